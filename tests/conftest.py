@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_oracle():
+    """The oracle is test infrastructure: imported by path, never by the product package."""
+    import importlib.util
+    p = os.path.join(ROOT, "oracle", "ddmp_oracle.py")
+    spec = importlib.util.spec_from_file_location("ddmp_oracle", p)
+    mod = sys.modules.get("ddmp_oracle")
+    if mod is None:
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["ddmp_oracle"] = mod
+        spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return load_oracle()

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference's importable modules.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test
+suite read the committed ``tests/golden/*.npz`` and never this script's imports.
+
+What is captured:
+  mesh_<name>.npz   reference ``Mesh(path)`` arrays for small synthetic meshes
+                    (util/mesh.py:8-21) + the OBJ text they were parsed from
+                    + ``Mesh.save`` output text (util/mesh.py:267-285)
+  loss_<name>.npz   values AND autograd gradients of the five training losses
+                    (util/loss.py:16,37,55,86,140) for seeded inputs, bnf loop in {1,5},
+                    plus mad / angular_difference (util/loss.py:261-277),
+                    Mesh.compute_face_normals on a displaced mesh (util/mesh.py:87-92) and
+                    models.compute_fn (util/models.py:5-10)
+
+``pymeshlab`` is stubbed at import (util/loss.py:4; only used at :279-284).
+``util/networks.py`` / ``util/datamaker.py`` cannot be imported (torch_geometric absent):
+the GCN stack has no golden vectors -> "parity unpinned" for it (see oracle/README.md).
+
+    python tests/golden/make_golden.py
+"""
+import io
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.modules["pymeshlab"] = types.SimpleNamespace(MeshSet=object)
+import util.loss as RefLoss          # noqa: E402
+import util.models as RefModels      # noqa: E402
+from util.mesh import Mesh as RefMesh  # noqa: E402
+
+from dual_dmp_amd import synth       # noqa: E402  (generators only: inputs, not outputs)
+
+
+def write_obj(path, vs, faces):
+    with open(path, "w") as fp:
+        for x, y, z in vs:
+            fp.write("v {0:.8f} {1:.8f} {2:.8f}\n".format(x, y, z))
+        for a, b, c in faces:
+            fp.write("f {0} {1} {2}\n".format(a + 1, b + 1, c + 1))
+
+
+def mesh_arrays(m):
+    v2v = m.v2v_mat
+    return dict(
+        vs=m.vs, faces=m.faces, edges=m.edges, f2f=m.f2f, f_edges=m.f_edges,
+        fn=m.fn, fa=m.fa, fc=m.fc, vn=m.vn, v_dims=m.v_dims.numpy(),
+        v2v_indices=v2v._indices().numpy(), v2v_values=v2v._values().numpy(),
+        vf_ptr=np.cumsum([0] + [len(s) for s in m.vf]),
+        vf_idx=np.concatenate([np.sort(list(s)) for s in m.vf]),
+        v2f_indices=m.v2f_mat._indices().numpy(),
+    )
+
+
+def grads(fn, *tensors):
+    leaves = [t.clone().requires_grad_(True) for t in tensors]
+    out = fn(*leaves)
+    if isinstance(out, tuple):
+        loss, extra = out
+    else:
+        loss, extra = out, None
+    g = torch.autograd.grad(loss, leaves, allow_unused=True)
+    g = [torch.zeros_like(l) if x is None else x for x, l in zip(g, leaves)]
+    return loss.detach(), extra, g
+
+
+def main():
+    meshes = {
+        "ico2": synth.icosphere(2),
+        "grid4": synth.open_grid(4, 4),
+        "cube3": synth.cube_cad(3),
+        "grid7x5": synth.open_grid(7, 5),
+    }
+    tmp = tempfile.mkdtemp()
+    for name, (vs, faces) in meshes.items():
+        # unit mean edge + noise so the geometry looks like a training input
+        gt, noisy, _ = synth.make_triplet(vs, faces)
+        path = os.path.join(tmp, name + ".obj")
+        write_obj(path, noisy.vs, faces)
+        obj_text = open(path).read()
+        m = RefMesh(path)
+        arrs = mesh_arrays(m)
+        spath = os.path.join(tmp, name + "_saved.obj")
+        m.save(spath)
+        np.savez_compressed(os.path.join(HERE, "mesh_%s.npz" % name),
+                            obj_text=np.frombuffer(obj_text.encode(), dtype=np.uint8),
+                            save_text=np.frombuffer(open(spath).read().encode(), dtype=np.uint8),
+                            **arrs)
+
+        # ---------------- losses
+        rng = np.random.default_rng(2718)
+        V, F = len(m.vs), len(m.faces)
+        pos = torch.tensor(m.vs + 0.05 * rng.standard_normal((V, 3)), dtype=torch.float32)
+        nrm = m.fn + 0.3 * rng.standard_normal((F, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        nrm = torch.tensor(nrm, dtype=torch.float32)
+        out = dict(pos=pos.numpy(), norm=nrm.numpy(), real_pos=m.vs, real_norm=m.fn)
+
+        l, _, g = grads(lambda p: RefLoss.pos_rec_loss(p, m.vs), pos)
+        out.update(pos_rec=l.numpy(), pos_rec_dpos=g[0].numpy())
+        l, _, g = grads(lambda p: RefLoss.mesh_laplacian_loss(p, m), pos)
+        out.update(lap=l.numpy(), lap_dpos=g[0].numpy())
+        l, _, g = grads(lambda n: RefLoss.norm_rec_loss(n, m.fn), nrm)
+        out.update(norm_rec=l.numpy(), norm_rec_dnorm=g[0].numpy())
+        for loop in (1, 5):
+            l, new_fn, g = grads(lambda p, n: RefLoss.fn_bnf_loss(p, n, m, loop=loop), pos, nrm)
+            out.update({"bnf%d" % loop: l.numpy(), "bnf%d_newfn" % loop: new_fn.detach().numpy(),
+                        "bnf%d_dnorm" % loop: g[1].numpy(), "bnf%d_dpos" % loop: g[0].numpy()})
+        l, _, g = grads(lambda p, n: RefLoss.pos_norm_loss(p, n, m), pos, nrm)
+        out.update(pos_norm=l.numpy(), pos_norm_dpos=g[0].numpy(), pos_norm_dnorm=g[1].numpy())
+
+        # the weighted sum exactly as main.py:106 forms it (k = 3,4,4,4,1), f64 by promotion
+        def total(p, n):
+            a = RefLoss.pos_rec_loss(p, m.vs)
+            b = RefLoss.mesh_laplacian_loss(p, m)
+            c = RefLoss.norm_rec_loss(n, m.fn)
+            d, _ = RefLoss.fn_bnf_loss(p, n, m, loop=1)
+            e = RefLoss.pos_norm_loss(p, n, m)
+            return 3.0 * a + 4.0 * b + 4.0 * c + 4.0 * d + 1.0 * e
+        l, _, g = grads(total, pos, nrm)
+        out.update(total=l.numpy(), total_dpos=g[0].numpy(), total_dnorm=g[1].numpy())
+
+        # ---------------- metric
+        out["mad"] = np.float64(RefLoss.mad(nrm, m.fn))
+        out["angdiff"] = RefLoss.angular_difference(nrm.numpy().astype(np.float64), m.fn)
+        m2 = RefMesh(path)
+        m2.vs = pos.numpy().astype(np.float64)
+        RefMesh.compute_face_normals(m2)
+        out.update(cfn_fn=m2.fn, cfn_fa=m2.fa, mad_pos=np.float64(RefLoss.mad(m2.fn, m.fn)))
+        out["models_compute_fn"] = RefModels.compute_fn(pos, m.faces).numpy()
+        np.savez_compressed(os.path.join(HERE, "loss_%s.npz" % name), **out)
+        print(name, "V", V, "F", F, "pos_rec", out["pos_rec"], out["pos_rec"].dtype,
+              "lap", out["lap"], "norm_rec", out["norm_rec"], "bnf1", out["bnf1"],
+              "bnf5", out["bnf5"], "pos_norm", out["pos_norm"], "mad", out["mad"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Vectorised Mesh builder == reference Mesh (golden) == loop oracle (random meshes)."""
+import os
+
+import numpy as np
+import pytest
+
+from dual_dmp_amd import synth
+from dual_dmp_amd.mesh import Mesh
+
+NAMES = ["ico2", "grid4", "cube3", "grid7x5"]
+
+
+def _check(m, ref):
+    assert m.vs.dtype == np.float64 and m.faces.dtype == np.int64
+    assert m.edges.dtype == np.int32 and np.array_equal(m.edges, ref["edges"])
+    assert m.f2f.dtype == np.int64 and m.f2f.shape == (len(m.faces), 3)
+    assert np.array_equal(np.sort(m.f2f, 1), np.sort(ref["f2f"], 1))
+    # padding sits at the end of the row, as in the reference
+    pad = m.f2f < 0
+    assert np.all(pad[:, :-1] <= pad[:, 1:])
+    assert m.f_edges.dtype == np.int64 and m.f_edges.shape == ref["f_edges"].shape
+    assert set(map(tuple, m.f_edges.T.tolist())) == set(map(tuple, ref["f_edges"].T.tolist()))
+    assert np.array_equal(m.f_edges[0], np.sort(m.f_edges[0]))          # grouped by face
+    assert np.array_equal(m.v_dims.numpy(), ref["v_dims"]) and m.v_dims.numpy().dtype == np.float32
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_mesh_matches_reference_golden(golden_dir, name, tmp_path):
+    g = np.load(os.path.join(golden_dir, "mesh_%s.npz" % name))
+    p = tmp_path / (name + ".obj")
+    p.write_bytes(g["obj_text"].tobytes())
+    m = Mesh(str(p))
+    assert np.array_equal(m.vs, g["vs"]) and np.array_equal(m.faces, g["faces"])
+    _check(m, g)
+    for k in ("fn", "fa", "fc"):
+        assert np.array_equal(getattr(m, k), g[k]), k
+    np.testing.assert_allclose(m.vn, g["vn"], rtol=1e-13, atol=1e-15)
+    assert np.array_equal(m.v2v_mat._indices().numpy(), g["v2v_indices"])
+    assert np.array_equal(m.v2v_mat._values().numpy(), g["v2v_values"])
+    assert np.array_equal(m.vf_ptr, g["vf_ptr"]) and np.array_equal(m.vf_idx, g["vf_idx"])
+    assert [sorted(s) for s in m.vf] == [g["vf_idx"][g["vf_ptr"][i]:g["vf_ptr"][i + 1]].tolist()
+                                         for i in range(len(m.vs))]
+    # column order inside a vertex row follows CPython set iteration in the reference
+    a, b = m.v2f_mat._indices().numpy(), g["v2f_indices"]
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(a[:, np.lexsort(a[::-1])], b[:, np.lexsort(b[::-1])])
+    # Mesh.save text format (util/mesh.py:267-285)
+    out = tmp_path / "saved.obj"
+    m.save(str(out))
+    assert out.read_bytes() == g["save_text"].tobytes()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_mesh_vs_loop_oracle_random_relabel(oracle, seed):
+    vs, faces = synth.icosphere(1) if seed % 2 == 0 else synth.open_grid(5, 4)
+    vs, faces = synth.permute_vertices(vs, faces, seed)
+    faces = synth.permute_faces(faces, seed)
+    rng = np.random.default_rng(seed)
+    roll = rng.integers(0, 3, len(faces))
+    faces = np.stack([np.roll(f, r) for f, r in zip(faces, roll)])
+    m = Mesh(vs=vs, faces=faces)
+    _check(m, oracle.mesh_tables_loops(vs, faces))
+
+
+def test_obj_parser_variants(tmp_path):
+    p = tmp_path / "t.obj"
+    p.write_text("# c\nv 0 0 0\nv 1 0 0\n\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nf 1/1/1 2/2/2 3/3/3\nf -4 -2 -1\n")
+    m = Mesh(str(p))
+    assert m.faces.tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert m.f2f.tolist() == [[1, -1, -1], [0, -1, -1]]
+    q = tmp_path / "q.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3 4\n")
+    with pytest.raises(AssertionError):
+        Mesh(str(q))
+
+
+def test_non_manifold_rejected():
+    vs = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1.0]])
+    faces = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4]])
+    with pytest.raises(ValueError):
+        Mesh(vs=vs, faces=faces)
+
+
+def test_generators_and_triplet():
+    v, f = synth.torus(20, 10)
+    assert len(v) == 200 and len(f) == 400
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    assert abs(synth.mean_edge_length(gt.vs, gt.edges) - 1.0) < 1e-12
+    assert (gt.f2f >= 0).all()
+    d_n = np.linalg.norm(noisy.vs - gt.vs, axis=1).mean()
+    d_s = np.linalg.norm(smooth.vs - gt.vs, axis=1).mean()
+    assert 0.05 < d_n < 0.4 and d_s > 0
+    v, f = synth.cube_cad(4)
+    m = Mesh(vs=v, faces=f)
+    assert len(f) == 12 * 16 and len(v) - m.edges_count + len(f) == 2
