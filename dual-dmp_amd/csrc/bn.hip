@@ -1,0 +1,311 @@
+// Train-mode BatchNorm1d + LeakyReLU over [N, C] node features (util/networks.py:31-44,51-62 of the
+// reference: bn_k(conv_k(.)) then LeakyReLU(0.01), batch statistics over ALL nodes, biased variance,
+// eps 1e-5, running stats with momentum 0.1).  HBM-bound streaming passes:
+//
+//   forward   stats : one read of Y  -> per-column (sum, sumsq) in float64 (per-thread f64 accumulators,
+//                     per-block partials, no atomics -> deterministic)            bytes = N*C*4
+//             the normalise+activate itself is NOT a pass: consumers (next GEMM / SpMM / head) apply
+//             z = LeakyReLU(scale[c]*y + shift[c]) as a load prologue; ddmp_bn_lrelu_apply_f32 exists for
+//             callers that want Z materialised.
+//   backward  reduce: one read of dZ and Y -> (sum g, sum g*yhat),  g = dZ * LeakyReLU'(scale*y+shift)
+//             apply : dY = scale*g + c1*y + c0  (c1, c0 fold the two batch means), optional column sums
+//                     of dY (= gradient of the conv bias, analytically 0 after BN).
+//
+// Column layout: C/4 lanes (float4) per row, 256/(C/4) rows per workgroup step, grid-stride over rows.
+#include "ddmp_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using namespace ddmp;
+
+constexpr int kMaxBlocks = 1024;
+
+__host__ __device__ inline bool width_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
+
+int colreduce_blocks(int64_t n_rows, int C) {
+    const int rpi = 256 / (C / 4);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, cdiv(n_rows, (int64_t)rpi * 4)));
+}
+
+// F::operator()(row, c0, s0[4], s1[4]) accumulates two per-column quantities for columns c0..c0+3
+template <class F>
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, int n_rows, int C, double* __restrict__ partial) {
+    __shared__ double sm[2 * 1024];
+    const int lpr = C >> 2, rpi = 256 / lpr;
+    const int tid = threadIdx.x, sl = tid % lpr, rg = tid / lpr;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int row = blockIdx.x * rpi + rg; row < n_rows; row += gridDim.x * rpi) f(row, sl * 4, s0, s1);
+    // sm[v][rg][c]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[rg * C + sl * 4 + k] = s0[k];
+        sm[1024 + rg * C + sl * 4 + k] = s1[k];
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * C; o += 256) {
+        const int v = o / C, c = o % C;
+        double t = 0.0;
+        for (int r = 0; r < rpi; ++r) t += sm[v * 1024 + r * C + c];
+        partial[(int64_t)blockIdx.x * 2 * C + o] = t;
+    }
+}
+
+struct StatsF {
+    const float* Y;
+    int64_t ldy;
+    __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
+        const float4 v = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + c0);
+        const double a = v.x, b = v.y, c = v.z, d = v.w;
+        s0[0] += a; s0[1] += b; s0[2] += c; s0[3] += d;
+        s1[0] = fma(a, a, s1[0]); s1[1] = fma(b, b, s1[1]); s1[2] = fma(c, c, s1[2]); s1[3] = fma(d, d, s1[3]);
+    }
+};
+
+struct BwdReduceF {
+    const float *dZ, *Y, *scale, *shift, *mean, *rstd;
+    int64_t lddz, ldy;
+    float slope;
+    __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
+        const float4 dz = *reinterpret_cast<const float4*>(dZ + (int64_t)row * lddz + c0);
+        const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + c0);
+        const float4 a = *reinterpret_cast<const float4*>(scale + c0);
+        const float4 b = *reinterpret_cast<const float4*>(shift + c0);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c0);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + c0);
+        const float g0 = dz.x * lrelu_grad(fmaf(y.x, a.x, b.x), slope);
+        const float g1 = dz.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope);
+        const float g2 = dz.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope);
+        const float g3 = dz.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope);
+        s0[0] += g0; s0[1] += g1; s0[2] += g2; s0[3] += g3;
+        s1[0] = fma((double)g0, (double)((y.x - mu.x) * rs.x), s1[0]);
+        s1[1] = fma((double)g1, (double)((y.y - mu.y) * rs.y), s1[1]);
+        s1[2] = fma((double)g2, (double)((y.z - mu.z) * rs.z), s1[2]);
+        s1[3] = fma((double)g3, (double)((y.w - mu.w) * rs.w), s1[3]);
+    }
+};
+
+// column sums of dY produced on the fly (bias gradient); second slot unused
+struct BwdApplyF {
+    const float *dZ, *Y, *scale, *shift, *c1, *c0;
+    float* dY;
+    int64_t lddz, ldy, lddy;
+    float slope;
+    __device__ __forceinline__ void operator()(int row, int cc, double* s0, double* s1) const {
+        const float4 dz = *reinterpret_cast<const float4*>(dZ + (int64_t)row * lddz + cc);
+        const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + cc);
+        const float4 a = *reinterpret_cast<const float4*>(scale + cc);
+        const float4 b = *reinterpret_cast<const float4*>(shift + cc);
+        const float4 k1 = *reinterpret_cast<const float4*>(c1 + cc);
+        const float4 k0 = *reinterpret_cast<const float4*>(c0 + cc);
+        float4 o;
+        o.x = fmaf(a.x, dz.x * lrelu_grad(fmaf(y.x, a.x, b.x), slope), fmaf(k1.x, y.x, k0.x));
+        o.y = fmaf(a.y, dz.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope), fmaf(k1.y, y.y, k0.y));
+        o.z = fmaf(a.z, dz.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope), fmaf(k1.z, y.z, k0.z));
+        o.w = fmaf(a.w, dz.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope), fmaf(k1.w, y.w, k0.w));
+        *reinterpret_cast<float4*>(dY + (int64_t)row * lddy + cc) = o;
+        s0[0] += o.x; s0[1] += o.y; s0[2] += o.z; s0[3] += o.w;
+        (void)s1;
+    }
+};
+
+struct ColsumF {
+    const float* X;
+    int64_t ldx;
+    __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
+        const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)row * ldx + c0);
+        s0[0] += v.x; s0[1] += v.y; s0[2] += v.z; s0[3] += v.w;
+        (void)s1;
+    }
+};
+
+// partial[nblk][width] -> out[width] (double); 64 columns x 4 slices per workgroup
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nblk,
+                                                              int width, double* __restrict__ out) {
+    __shared__ double sm[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    double t = 0.0;
+    if (c < width)
+        for (int b = sl; b < nblk; b += 4) t += partial[(int64_t)b * width + c];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    if (sl == 0 && c < width) out[c] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
+}
+
+__global__ void bn_prepare_kernel(const double* __restrict__ sums, double n_total, int C,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                  float momentum, float* __restrict__ scale, float* __restrict__ shift,
+                                  float* __restrict__ mean, float* __restrict__ rstd,
+                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / n_total;
+    double var = sums[C + c] / n_total - mu * mu;   // biased
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    const float a = gamma[c] * rs;
+    scale[c] = a;
+    shift[c] = fmaf(-muf, a, beta[c]);
+    mean[c] = muf;
+    rstd[c] = rs;
+    if (running_mean) {
+        const double unb = n_total > 1.0 ? var * n_total / (n_total - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_bwd_prepare_kernel(const double* __restrict__ sums2, double n_total, int C,
+                                      const float* __restrict__ scale, const float* __restrict__ mean,
+                                      const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double db = sums2[c], dg = sums2[C + c];
+    dbeta[c] = (float)db;
+    dgamma[c] = (float)dg;
+    const double a = scale[c], r = rstd[c], mu = mean[c];
+    const double k1 = -a * r * dg / n_total;
+    c1[c] = (float)k1;
+    c0[c] = (float)(-a * db / n_total - k1 * mu);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+__global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __restrict__ Y, int64_t ldy,
+                                                             float* __restrict__ Z, int64_t ldz, int64_t n_rows,
+                                                             int C, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float slope) {
+    const int q = C >> 2;
+    const int64_t total = n_rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / q;
+        const int c0 = (int)(i % q) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(Y + row * ldy + c0);
+        const float4 a = *reinterpret_cast<const float4*>(scale + c0);
+        const float4 b = *reinterpret_cast<const float4*>(shift + c0);
+        *reinterpret_cast<float4*>(Z + row * ldz + c0) = f4_affine_lrelu(v, a, b, slope);
+    }
+}
+
+template <class F>
+int run_colreduce(const F& f, int64_t n_rows, int C, int width, double* out, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+    const int nblk = colreduce_blocks(n_rows, C);
+    if (!ws || ws_bytes < (size_t)nblk * 2 * C * sizeof(double)) return DDMP_EWORKSPACE;
+    double* partial = (double*)ws;
+    hipLaunchKernelGGL((colreduce_kernel<F>), dim3(nblk), dim3(256), 0, st, f, (int)n_rows, C, partial);
+    LAUNCH_TRY();
+    // partial rows are [2*C]; reduce the first `width` columns (width = C or 2C)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(2 * C, 64)), dim3(256), 0, st, partial, nblk,
+                       2 * C, out);
+    LAUNCH_TRY();
+    (void)width;
+    return DDMP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ddmp_colreduce_workspace_bytes(int64_t n_rows, int C) {
+    if (n_rows <= 0 || !width_ok(C)) return 0;
+    // partials + room for one [2C] double result used by calls that only export part of it
+    return ((size_t)colreduce_blocks(n_rows, C) * 2 * C + 2 * (size_t)C) * sizeof(double);
+}
+
+extern "C" int ddmp_bn_stats_f32(const float* Y, int64_t ldy, int64_t n_rows, int C, double* sums,
+                                 void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && ldy % 4 == 0);
+    StatsF f{Y, ldy};
+    return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ddmp_bn_prepare_f32(const double* sums, double n_total, int C, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* scale,
+                                   float* shift, float* mean, float* rstd, float* running_mean,
+                                   float* running_var, ddmp_stream stream) {
+    ARG_TRY(sums && n_total > 0 && C > 0 && gamma && beta && scale && shift && mean && rstd);
+    ARG_TRY((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums,
+                       n_total, C, gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean,
+                       running_var);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_bn_lrelu_apply_f32(const float* Y, int64_t ldy, float* Z, int64_t ldz, int64_t n_rows,
+                                       int C, const float* scale, const float* shift, float slope,
+                                       ddmp_stream stream) {
+    ARG_TRY(Y && Z && scale && shift && n_rows > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0);
+    ARG_TRY(ldy >= C && ldz >= C);
+    const int64_t total = n_rows * (C / 4);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 8);
+    hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Y, ldy, Z, ldz,
+                       n_rows, C, scale, shift, slope);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy,
+                                      int64_t n_rows, int C, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, float slope, double* sums2,
+                                      void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
+    ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && lddz >= C && ldy % 4 == 0 && lddz % 4 == 0);
+    BwdReduceF f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
+    return run_colreduce(f, n_rows, C, 2 * C, sums2, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const float* scale,
+                                       const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                       float* c1, float* c0, ddmp_stream stream) {
+    ARG_TRY(sums2 && n_total > 0 && C > 0 && scale && mean && rstd && dgamma && dbeta && c1 && c0);
+    hipLaunchKernelGGL(bn_bwd_prepare_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream,
+                       sums2, n_total, C, scale, mean, rstd, dgamma, dbeta, c1, c0);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, float* dY,
+                                     int64_t lddy, int64_t n_rows, int C, const float* scale,
+                                     const float* shift, const float* c1, const float* c0, float slope,
+                                     double* dbias_sums, void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0 && dbias_sums);
+    ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C));
+    ARG_TRY(ldy >= C && lddz >= C && lddy >= C && ldy % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0);
+    BwdApplyF f{dZ, Y, scale, shift, c1, c0, dY, lddz, ldy, lddy, slope};
+    // result buffer [2C] sits behind the partials in the workspace; only the first C are the column sums
+    const int nblk = colreduce_blocks(n_rows, C);
+    const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
+    if (!ws || ws_bytes < need) return DDMP_EWORKSPACE;
+    double* tmp = (double*)ws + (size_t)nblk * 2 * C;
+    int st = run_colreduce(f, n_rows, C, C, tmp, ws, (size_t)nblk * 2 * C * sizeof(double), (hipStream_t)stream);
+    if (st != DDMP_OK) return st;
+    HIP_TRY(hipMemcpyAsync(dbias_sums, tmp, sizeof(double) * (size_t)C, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_colsum_f32(const float* X, int64_t ldx, int64_t n_rows, int C, double* sums /*[C]*/,
+                               void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(X && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldx >= C && ldx % 4 == 0);
+    ColsumF f{X, ldx};
+    const int nblk = colreduce_blocks(n_rows, C);
+    const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
+    if (!ws || ws_bytes < need) return DDMP_EWORKSPACE;
+    double* tmp = (double*)ws + (size_t)nblk * 2 * C;
+    int st = run_colreduce(f, n_rows, C, C, tmp, ws, (size_t)nblk * 2 * C * sizeof(double), (hipStream_t)stream);
+    if (st != DDMP_OK) return st;
+    HIP_TRY(hipMemcpyAsync(sums, tmp, sizeof(double) * (size_t)C, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_stream stream) {
+    ARG_TRY(in && out && n > 0 && n < INT32_MAX);
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, (int)n);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}

@@ -1,0 +1,84 @@
+// Shared definitions for libddmp_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/ddmp_hip.h"
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e__ = (expr);                       \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)
+
+#define LAUNCH_TRY()                                   \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)
+
+#define ARG_TRY(cond)                                  \
+    do {                                               \
+        if (!(cond)) return DDMP_EINVAL;               \
+    } while (0)
+
+namespace ddmp {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kXcd = 8;            // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+constexpr int kCu = 256;
+
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// LeakyReLU with the slope as a runtime value (reference: nn.LeakyReLU() = 0.01)
+__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : slope * x; }
+__device__ __forceinline__ float lrelu_grad(float x, float slope) { return x > 0.f ? 1.f : slope; }
+
+__device__ __forceinline__ float4 f4_affine_lrelu(float4 v, float4 a, float4 b, float slope) {
+    v.x = lrelu(fmaf(v.x, a.x, b.x), slope);
+    v.y = lrelu(fmaf(v.y, a.y, b.y), slope);
+    v.z = lrelu(fmaf(v.z, a.z, b.z), slope);
+    v.w = lrelu(fmaf(v.w, a.w, b.w), slope);
+    return v;
+}
+
+// wave-level sum (all 64 lanes end with the total)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-level sum of one double per thread; result valid in thread 0. `sm` holds >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sm[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) t += sm[i];
+    }
+    return t;
+}
+
+}  // namespace ddmp
+
+// the CSR graph handle (opaque in the C ABI)
+struct ddmp_graph {
+    int64_t n_rows;     // rows that are aggregated (owned nodes)
+    int64_t n_cols;     // nodes that can be referenced by col (owned + halo); >= n_rows
+    int64_t nnz;        // entries, self loops included
+    int32_t* rowptr;    // device [n_rows + 1]
+    int32_t* col;       // device [nnz]
+    float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
+    int max_row_nnz;
+};

@@ -1,0 +1,415 @@
+// Dense per-node feature x weight contractions on the matrix cores, exact f32
+// (v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, 157.3 TF peak on MI355X; gfx950 has no TF32).
+//
+//   nt / nn :  Y[n, M] = f(A[n, K]) . op(B)  (+ bias)      tall-skinny: n = 0.5-8 M rows, K, M <= 512
+//   tn      :  dW[M, K] = G[n, M]^T . f(Z[n, K])            reduction over the n rows, split over blocks
+//
+// Tiling for 64-wide wavefronts: a 256-thread workgroup (4 waves as 2x2) owns a 128 x (32*2*TN) output
+// tile; each wave owns (2 x TN) MFMA tiles of 32x32 (16 accumulator VGPRs each).  Operands go
+// global -> registers (fused BatchNorm+LeakyReLU prologue on A / Z) -> LDS (double buffered, one barrier
+// per K tile) -> ds_read_b128 fragments.  The K order inside an 8-wide group is permuted so that one
+// b128 read feeds four consecutive MFMAs (lane half h supplies k = 8*kk + 4*h + s for step s): the sum
+// over k is the same set of products.  Row stride 36 floats keeps the b128 fragment reads
+// bank-conflict free (36*r mod 64 = 4*(9r mod 16), distinct for the 16 rows of a lane group).
+//
+// blockIdx is XCD-aware: the column tiles of one row panel are adjacent on ONE XCD, so the A panel is
+// fetched from HBM once and re-read from that XCD's L2; W (<= 1 MiB) lives in every L2.
+#include "ddmp_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using namespace ddmp;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128;      // rows per block tile
+constexpr int kBK = 32;       // K per LDS tile
+constexpr int kLd = kBK + 4;  // LDS row stride (floats)
+
+// ------------------------------------------------------------------------------------------------
+//  Y = f(A) . W^T (B_KMAJOR = false, W is [M,K])   or   Y = A . W (B_KMAJOR = true, W is [K_red, M_out])
+//  generic naming inside: A[n, KD] (reduction dim KD), B gives Bs[m][k], Y[n, MD]
+// ------------------------------------------------------------------------------------------------
+template <int TN, bool B_KMAJOR, bool PRO>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+    float* __restrict__ Y, int64_t ldy, int n_rows, int KD, int MD,
+    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float slope, int n_row_tiles, int n_col_tiles) {
+    constexpr int BN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float As[2][kBM * kLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * kLd];
+
+    // XCD-aware tile id: consecutive ids on one XCD share the row panel
+    const int per_xcd = (int)cdiv((int64_t)n_row_tiles, kXcd) * n_col_tiles;
+    const int lin = (blockIdx.x & (kXcd - 1)) * per_xcd + (blockIdx.x >> 3);
+    const int row_tile = lin / n_col_tiles, col_tile = lin % n_col_tiles;
+    if (row_tile >= n_row_tiles) return;
+    const int row0 = row_tile * kBM, col0 = col_tile * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // staging assignment: thread -> (k quad, row) ; 8 quads per row, 32 rows per pass
+    const int kq = tid & 7, rr = tid >> 3;
+    float4 ra[4], rb[(B_KMAJOR ? 4 : BN / 32)];
+
+    auto load_tiles = [&](int k0) {
+        const int kcol = k0 + kq * 4;
+        float4 sc, sh;
+        if (PRO && kcol < KD) {
+            sc = *reinterpret_cast<const float4*>(pscale + kcol);
+            sh = *reinterpret_cast<const float4*>(pshift + kcol);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = row0 + p * 32 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n_rows && kcol < KD) {
+                v = *reinterpret_cast<const float4*>(A + (int64_t)r * lda + kcol);
+                if (PRO) v = f4_affine_lrelu(v, sc, sh, slope);
+            }
+            ra[p] = v;
+        }
+        if (!B_KMAJOR) {
+#pragma unroll
+            for (int p = 0; p < BN / 32; ++p) {
+                const int m = col0 + p * 32 + rr;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < MD && kcol < KD) v = *reinterpret_cast<const float4*>(B + (int64_t)m * ldb + kcol);
+                rb[p] = v;
+            }
+        } else {
+            // B[k][m]: thread -> (m quad, k row): BN/4 quads per k row
+            constexpr int QPR = BN / 4, KPP = 256 / QPR, NP = kBK / KPP;
+            static_assert(NP <= 4, "rb too small");
+            const int mq = tid % QPR, kr = tid / QPR;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int k = k0 + p * KPP + kr, m = col0 + mq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < KD && m < MD) v = *reinterpret_cast<const float4*>(B + (int64_t)k * ldb + m);
+                rb[p] = v;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<float4*>(&As[buf][(p * 32 + rr) * kLd + kq * 4]) = ra[p];
+        if (!B_KMAJOR) {
+#pragma unroll
+            for (int p = 0; p < BN / 32; ++p)
+                *reinterpret_cast<float4*>(&Bs[buf][(p * 32 + rr) * kLd + kq * 4]) = rb[p];
+        } else {
+            constexpr int QPR = BN / 4, KPP = 256 / QPR, NP = kBK / KPP;
+            const int mq = tid % QPR, kr = tid / QPR;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int k = p * KPP + kr;
+                Bs[buf][(mq * 4 + 0) * kLd + k] = rb[p].x;
+                Bs[buf][(mq * 4 + 1) * kLd + k] = rb[p].y;
+                Bs[buf][(mq * 4 + 2) * kLd + k] = rb[p].z;
+                Bs[buf][(mq * 4 + 3) * kLd + k] = rb[p].w;
+            }
+        }
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (KD + kBK - 1) / kBK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles((kt + 1) * kBK);
+        const float* as = &As[buf][(wm * 64 + l31) * kLd + lh * 4];
+        const float* bs = &Bs[buf][(wn * 32 * TN + l31) * kLd + lh * 4];
+#pragma unroll
+        for (int kk = 0; kk < kBK / 8; ++kk) {
+            float4 af[2], bf[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLd + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * kLd + kk * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: reg r -> row (r&3) + 8*(r>>2) + 4*lh, col l31
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = col0 + wn * 32 * TN + j * 32 + l31;
+        if (c >= MD) continue;
+        const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < n_rows) Y[(int64_t)row * ldy + c] = acc[i][j][r] + bv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  wgrad: partial[s][m][k] = sum_{rows of split s} G[row][m] * f(Z[row][k])
+//  block tile (64*T) x (64*T) of dW; rows consumed 32 at a time; both operands are row(k)-major so
+//  fragments are conflict-free ds_read_b32 (consecutive lanes -> consecutive floats).
+// ------------------------------------------------------------------------------------------------
+template <int T, bool PRO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(
+    const float* __restrict__ G, int64_t ldg, const float* __restrict__ Z, int64_t ldz,
+    float* __restrict__ out, int64_t ld_out, int64_t split_stride, int n_rows, int M, int K,
+    int rows_per_split, int n_tiles_m, int n_tiles_k, int n_splits,
+    const float* __restrict__ pscale, const float* __restrict__ pshift, float slope) {
+    constexpr int BT = 64 * T;                 // tile edge
+    constexpr int QPR = BT / 4;                // float4 per tile row
+    constexpr int RPP = 256 / QPR;             // rows per pass
+    constexpr int NP = 32 / RPP;               // passes per 32-row tile
+    __shared__ __attribute__((aligned(16))) float Gs[2][32 * BT];
+    __shared__ __attribute__((aligned(16))) float Zs[2][32 * BT];
+
+    // same-split tiles adjacent on one XCD (they share the G / Z row panels through L2)
+    const int n_tiles = n_tiles_m * n_tiles_k;
+    const int xcd = blockIdx.x & (kXcd - 1), local = blockIdx.x >> 3;
+    const int tile = local % n_tiles;
+    const int split = (local / n_tiles) * kXcd + xcd;
+    if (split >= n_splits) return;
+    const int tm0 = (tile / n_tiles_k) * BT, tk0 = (tile % n_tiles_k) * BT;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_rows, r_begin + rows_per_split);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q = tid % QPR, pr = tid / QPR;
+
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int zc = tk0 + q * 4, gc = tm0 + q * 4;
+    if (PRO && zc < K) {
+        sc = *reinterpret_cast<const float4*>(pscale + zc);
+        sh = *reinterpret_cast<const float4*>(pshift + zc);
+    }
+    float4 rg[NP], rz[NP];
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = r0 + p * RPP + pr;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f), z = g;
+            if (r < r_end) {
+                if (gc < M) g = *reinterpret_cast<const float4*>(G + (int64_t)r * ldg + gc);
+                if (zc < K) {
+                    z = *reinterpret_cast<const float4*>(Z + (int64_t)r * ldz + zc);
+                    if (PRO) z = f4_affine_lrelu(z, sc, sh, slope);
+                }
+            }
+            rg[p] = g;
+            rz[p] = z;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            *reinterpret_cast<float4*>(&Gs[buf][(p * RPP + pr) * BT + q * 4]) = rg[p];
+            *reinterpret_cast<float4*>(&Zs[buf][(p * RPP + pr) * BT + q * 4]) = rz[p];
+        }
+    };
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nt = (r_end - r_begin + 31) / 32;
+    if (nt > 0) {
+        load_tiles(r_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tiles(r_begin + (t + 1) * 32);
+        const float* gs = &Gs[buf][lh * BT + wm * 32 * T + l31];
+        const float* zs = &Zs[buf][lh * BT + wn * 32 * T + l31];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            float a[T], b[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) a[i] = gs[ks * 2 * BT + i * 32];
+#pragma unroll
+            for (int j = 0; j < T; ++j) b[j] = zs[ks * 2 * BT + j * 32];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* o = out + (int64_t)split * split_stride;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int k = tk0 + wn * 32 * T + j * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tm0 + wm * 32 * T + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) o[(int64_t)m * ld_out + k] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int64_t split_stride,
+                                                            int n_splits, float* __restrict__ dW, int64_t lddw,
+                                                            int M, int K) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * K) return;
+    const int m = idx / K, k = idx % K;
+    double s = 0.0;
+    for (int i = 0; i < n_splits; ++i) s += (double)part[(int64_t)i * split_stride + idx];
+    dW[(int64_t)m * lddw + k] = (float)s;
+}
+
+struct TnPlan {
+    int T, n_tiles_m, n_tiles_k, n_splits, rows_per_split;
+};
+
+TnPlan tn_plan(int64_t n_rows, int M, int K) {
+    TnPlan p;
+    p.T = (M >= 128 && K >= 128) ? 2 : 1;
+    const int bt = 64 * p.T;
+    p.n_tiles_m = (int)cdiv(M, bt);
+    p.n_tiles_k = (int)cdiv(K, bt);
+    const int tiles = p.n_tiles_m * p.n_tiles_k;
+    // aim at ~3 workgroups per CU; at least 512 rows per split; multiple of 8 splits (XCD mapping)
+    int64_t want = std::max<int64_t>(1, (3 * kCu) / tiles);
+    int64_t max_by_rows = std::max<int64_t>(1, n_rows / 512);
+    int64_t s = std::min(want, max_by_rows);
+    s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
+    int64_t rps = cdiv(n_rows, s);
+    rps = cdiv(rps, 32) * 32;
+    p.rows_per_split = (int)rps;
+    p.n_splits = (int)cdiv(n_rows, rps);
+    return p;
+}
+
+}  // namespace
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y,
+                                int64_t ldy, int64_t n_rows, int K, int M, const float* bias,
+                                const float* pro_scale, const float* pro_shift, float slope,
+                                ddmp_stream stream) {
+    ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
+    ARG_TRY(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldy >= M);
+    ARG_TRY(aligned16(A) && aligned16(W));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
+    hipStream_t st = (hipStream_t)stream;
+    const int n_row_tiles = (int)cdiv(n_rows, kBM);
+    const int TN = M > 64 ? 2 : 1;
+    const int n_col_tiles = (int)cdiv(M, 64 * TN);
+    dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+#define DDMP_LAUNCH_NT(TN_, PRO_)                                                                       \
+    hipLaunchKernelGGL((gemm_rows_kernel<TN_, false, PRO_>), grid, block, 0, st, A, lda, W, ldw, Y, ldy, \
+                       (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, n_row_tiles, n_col_tiles)
+    if (TN == 2) {
+        if (pro_scale) DDMP_LAUNCH_NT(2, true); else DDMP_LAUNCH_NT(2, false);
+    } else {
+        if (pro_scale) DDMP_LAUNCH_NT(1, true); else DDMP_LAUNCH_NT(1, false);
+    }
+#undef DDMP_LAUNCH_NT
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y,
+                                int64_t ldy, int64_t n_rows, int M, int K, ddmp_stream stream) {
+    // Y[n,K] = A[n,M] . W[M,K] : reduction over M, output width K
+    ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
+    ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ldy >= K);
+    ARG_TRY(aligned16(A) && aligned16(W));
+    hipStream_t st = (hipStream_t)stream;
+    const int n_row_tiles = (int)cdiv(n_rows, kBM);
+    const int TN = K > 64 ? 2 : 1;
+    const int n_col_tiles = (int)cdiv(K, 64 * TN);
+    dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+    if (TN == 2)
+        hipLaunchKernelGGL((gemm_rows_kernel<2, true, false>), grid, block, 0, st, A, lda, W, ldw, Y, ldy,
+                           (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles);
+    else
+        hipLaunchKernelGGL((gemm_rows_kernel<1, true, false>), grid, block, 0, st, A, lda, W, ldw, Y, ldy,
+                           (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K) {
+    if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
+    TnPlan p = tn_plan(n_rows, M, K);
+    return (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+}
+
+extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW,
+                                int64_t lddw, int64_t n_rows, int M, int K, const float* pro_scale,
+                                const float* pro_shift, float slope, void* workspace,
+                                size_t workspace_bytes, ddmp_stream stream) {
+    ARG_TRY(G && Z && dW && n_rows > 0 && M > 0 && K > 0 && n_rows < INT32_MAX);
+    ARG_TRY(M % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldg >= M && ldz >= K && lddw >= K);
+    ARG_TRY(aligned16(G) && aligned16(Z));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
+    hipStream_t st = (hipStream_t)stream;
+    TnPlan p = tn_plan(n_rows, M, K);
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
+    float* part = (float*)workspace;
+    const int64_t sstride = (int64_t)M * K;
+    const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(256);
+#define DDMP_LAUNCH_TN(T_, PRO_)                                                                          \
+    hipLaunchKernelGGL((gemm_tn_kernel<T_, PRO_>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K,  \
+                       sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, \
+                       pro_scale, pro_shift, slope)
+    if (p.T == 2) {
+        if (pro_scale) DDMP_LAUNCH_TN(2, true); else DDMP_LAUNCH_TN(2, false);
+    } else {
+        if (pro_scale) DDMP_LAUNCH_TN(1, true); else DDMP_LAUNCH_TN(1, false);
+    }
+#undef DDMP_LAUNCH_TN
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, st, part,
+                       sstride, p.n_splits, dW, lddw, M, K);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}

@@ -1,0 +1,177 @@
+// Graph handle: CSR of A + I with D^-1/2, built once (the reference recomputes gcn_norm on every
+// GCNConv call, 24x per step, on a static mesh graph).  Host-side counting sort; one-off.
+#include "ddmp_common.h"
+
+#include <algorithm>
+#include <new>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+extern "C" int ddmp_abi_version(void) { return DDMP_ABI_VERSION; }
+
+extern "C" const char* ddmp_status_string(int status) {
+    switch (status) {
+        case DDMP_OK: return "ok";
+        case DDMP_EINVAL: return "invalid argument";
+        case DDMP_ERANGE: return "index out of range";
+        case DDMP_ENOMEM: return "host allocation failed";
+        case DDMP_EWORKSPACE: return "workspace too small";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}
+
+extern "C" int ddmp_csr_build_host(int64_t n, int64_t nnz, const int64_t* ei, int32_t* rowptr,
+                                   int32_t* col, float* dinv, int64_t* nnz_out) {
+    ARG_TRY(n > 0 && nnz >= 0 && rowptr && col && dinv && nnz_out);
+    ARG_TRY(nnz == 0 || ei);
+    ARG_TRY(n < (int64_t)INT32_MAX && nnz + n < (int64_t)INT32_MAX);
+    const int64_t* src = ei;
+    const int64_t* dst = ei + nnz;
+    std::vector<int32_t> cnt;
+    try { cnt.assign((size_t)n + 1, 0); } catch (const std::bad_alloc&) { return DDMP_ENOMEM; }
+    int64_t kept = 0;
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int64_t s = src[e], d = dst[e];
+        if (s < 0 || s >= n || d < 0 || d >= n) return DDMP_ERANGE;
+        if (s == d) continue;                         // add_remaining_self_loops drops explicit loops
+        cnt[(size_t)d + 1]++;
+        kept++;
+    }
+    if (*nnz_out < kept + n) return DDMP_EWORKSPACE;
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t deg = cnt[(size_t)i + 1] + 1;   // + the self loop
+        rowptr[i + 1] = rowptr[i] + deg;
+        dinv[i] = (float)(1.0 / std::sqrt((double)deg));
+    }
+    // fill: cursor per row
+    for (int64_t i = 0; i < n; ++i) cnt[(size_t)i] = rowptr[i];
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int64_t s = src[e], d = dst[e];
+        if (s == d) continue;
+        col[cnt[(size_t)d]++] = (int32_t)s;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        col[cnt[(size_t)i]++] = (int32_t)i;
+        std::sort(col + rowptr[i], col + rowptr[i + 1]);
+    }
+    *nnz_out = kept + n;
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_csr_bfs_order_host(int64_t n, const int32_t* rowptr, const int32_t* col,
+                                       int32_t* order) {
+    ARG_TRY(n > 0 && rowptr && col && order);
+    std::vector<uint8_t> seen;
+    try { seen.assign((size_t)n, 0); } catch (const std::bad_alloc&) { return DDMP_ENOMEM; }
+    int64_t head = 0, tail = 0;
+    for (int64_t seed = 0; seed < n; ++seed) {
+        if (seen[(size_t)seed]) continue;
+        seen[(size_t)seed] = 1;
+        order[tail++] = (int32_t)seed;
+        while (head < tail) {
+            const int32_t u = order[head++];
+            for (int32_t e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+                const int32_t v = col[e];
+                if (v < 0 || v >= n) return DDMP_ERANGE;
+                if (!seen[(size_t)v]) {
+                    seen[(size_t)v] = 1;
+                    order[tail++] = v;
+                }
+            }
+        }
+    }
+    return DDMP_OK;
+}
+
+static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                        const float* dinv, ddmp_graph** out) {
+    ddmp_graph* g = new (std::nothrow) ddmp_graph();
+    if (!g) return DDMP_ENOMEM;
+    std::memset(g, 0, sizeof(*g));
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = rowptr[n_rows];
+    int mx = 0;
+    for (int64_t i = 0; i < n_rows; ++i) mx = std::max(mx, (int)(rowptr[i + 1] - rowptr[i]));
+    g->max_row_nnz = mx;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&g->rowptr, sizeof(int32_t) * (size_t)(n_rows + 1))) != hipSuccess) goto fail;
+    if ((e = hipMalloc((void**)&g->col, sizeof(int32_t) * (size_t)std::max<int64_t>(g->nnz, 1))) != hipSuccess) goto fail;
+    if ((e = hipMalloc((void**)&g->dinv, sizeof(float) * (size_t)n_cols)) != hipSuccess) goto fail;
+    if ((e = hipMemcpy(g->rowptr, rowptr, sizeof(int32_t) * (size_t)(n_rows + 1), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    if (g->nnz > 0 &&
+        (e = hipMemcpy(g->col, col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    *out = g;
+    return DDMP_OK;
+fail:
+    ddmp_graph_destroy(g);
+    return (int)e;
+}
+
+extern "C" int ddmp_graph_create_csr_host(int64_t n_rows, int64_t n_cols, const int32_t* rowptr,
+                                          const int32_t* col, const float* dinv, ddmp_graph** out) {
+    ARG_TRY(out && n_rows > 0 && n_cols >= n_rows && rowptr && col && dinv);
+    ARG_TRY(rowptr[0] == 0);
+    for (int64_t i = 0; i < n_rows; ++i) ARG_TRY(rowptr[i + 1] >= rowptr[i]);
+    for (int64_t e = 0; e < rowptr[n_rows]; ++e)
+        if (col[e] < 0 || col[e] >= n_cols) return DDMP_ERANGE;
+    return upload_graph(n_rows, n_cols, rowptr, col, dinv, out);
+}
+
+extern "C" int ddmp_graph_create(int64_t n, int64_t nnz, const int64_t* edge_index, int on_device,
+                                 ddmp_graph** out) {
+    ARG_TRY(out && n > 0 && nnz >= 0 && (nnz == 0 || edge_index));
+    std::vector<int64_t> host_ei;
+    std::vector<int32_t> rowptr, col;
+    std::vector<float> dinv;
+    try {
+        rowptr.resize((size_t)n + 1);
+        col.resize((size_t)(nnz + n));
+        dinv.resize((size_t)n);
+        if (on_device && nnz > 0) host_ei.resize((size_t)(2 * nnz));
+    } catch (const std::bad_alloc&) {
+        return DDMP_ENOMEM;
+    }
+    const int64_t* ei = edge_index;
+    if (on_device && nnz > 0) {
+        HIP_TRY(hipMemcpy(host_ei.data(), edge_index, sizeof(int64_t) * (size_t)(2 * nnz), hipMemcpyDeviceToHost));
+        ei = host_ei.data();
+    }
+    int64_t used = nnz + n;
+    int st = ddmp_csr_build_host(n, nnz, ei, rowptr.data(), col.data(), dinv.data(), &used);
+    if (st != DDMP_OK) return st;
+    return upload_graph(n, n, rowptr.data(), col.data(), dinv.data(), out);
+}
+
+extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
+    if (!g) return DDMP_OK;
+    if (g->rowptr) (void)hipFree(g->rowptr);
+    if (g->col) (void)hipFree(g->col);
+    if (g->dinv) (void)hipFree(g->dinv);
+    delete g;
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz,
+                               int* max_row_nnz) {
+    ARG_TRY(g);
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    if (max_row_nnz) *max_row_nnz = g->max_row_nnz;
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t** col,
+                                 const float** dinv) {
+    ARG_TRY(g);
+    if (rowptr) *rowptr = g->rowptr;
+    if (col) *col = g->col;
+    if (dinv) *dinv = g->dinv;
+    return DDMP_OK;
+}

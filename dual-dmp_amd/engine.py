@@ -1,0 +1,252 @@
+"""Fused GCN-stack engine: forward / backward of one PosNet / NormalNet trunk + head on the HIP kernels.
+
+What the reference runs per net and step (util/networks.py:47-67, :108-130) as
+12 x [GCNConv -> BatchNorm1d -> LeakyReLU] + 2 Linear becomes, per layer:
+
+  aggregate-first (C_in <  C_out):  P = A_hat . f(Y_prev)        ddmp_spmm_f32   (prologue f fused)
+                                    Y = P . W^T + b              ddmp_gemm_nt_f32
+  transform-first (C_in >= C_out):  H = f(Y_prev) . W^T          ddmp_gemm_nt_f32 (prologue f fused)
+                                    Y = A_hat . H + b            ddmp_spmm_f32
+  statistics                        (sum, sumsq) of Y  -> scale/shift   ddmp_bn_stats_f32 + ddmp_bn_prepare_f32
+
+f = LeakyReLU(BatchNorm(.)) of the previous layer is never materialised: only the conv outputs Y_l are
+stored (and P_l where the weight gradient needs it).  A_hat.(X W^T) == (A_hat.X) W^T, so the aggregation
+always runs on min(C_in, C_out) channels (sum C = 2000 instead of the reference order's 2496).
+P_1 = A_hat.X_0 is constant (static graph, static input) and computed once.
+
+Multi-device: rows [0, n_rows) are owned, rows [n_rows, n_cols) are the 1-hop halo.  The tensor about
+to be gathered is the only thing exchanged (``comm.halo_exchange``), BatchNorm column sums and weight
+gradients are all-reduced (``comm.all_reduce_sum``).  ``comm`` defaults to the single-device no-op.
+
+Parameter arena (float32, one flat buffer per net; every tensor 16-byte aligned):
+  layer l = 1..12:  W_l [C_out, C_in_padded] | b_l [C_out] | gamma_l [C_out] | beta_l [C_out]
+  head:             W1 [16,32] | b1 [16] | W2 [3,16] | b2 [3]
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .ops import SLOPE
+
+POS_WIDTHS = [16, 32, 64, 128, 256, 256, 512, 512, 256, 256, 128, 64, 32, 16, 3]    # util/networks.py:13
+NORM_WIDTHS = [7, 32, 64, 128, 256, 256, 512, 512, 256, 256, 128, 64, 32, 16, 3]    # util/networks.py:74
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class NoComm:
+    """Single-device communicator: nothing to exchange."""
+    world_size = 1
+    rank = 0
+
+    def halo_exchange(self, t, n_rows):
+        return t
+
+    def all_reduce_sum(self, t):
+        return t
+
+
+class ArenaLayout:
+    """Offsets (in floats) of every parameter tensor inside the flat arena."""
+
+    def __init__(self, widths: List[int]):
+        assert len(widths) == 15 and widths[12:] == [32, 16, 3]
+        self.widths = list(widths)
+        self.cin = [widths[0]] + widths[1:12]                 # true fan-in per conv
+        self.cin_p = [_pad4(c) for c in self.cin]             # stored (padded) fan-in
+        self.cout = widths[1:13]
+        self.entries = []                                     # (name, offset, stored_shape, true_shape)
+        off = 0
+
+        def add(name, stored, true=None):
+            nonlocal off
+            n = 1
+            for s in stored:
+                n *= s
+            self.entries.append((name, off, tuple(stored), tuple(true or stored)))
+            off += (n + 3) // 4 * 4
+
+        for l in range(12):
+            i = l + 1
+            add("conv%d.lin.weight" % i, (self.cout[l], self.cin_p[l]), (self.cout[l], self.cin[l]))
+            add("conv%d.bias" % i, (self.cout[l],))
+            add("bn%d.weight" % i, (self.cout[l],))
+            add("bn%d.bias" % i, (self.cout[l],))
+        add("linear1.weight", (16, 32))
+        add("linear1.bias", (16,))
+        add("linear2.weight", (3, 16))
+        add("linear2.bias", (3,))
+        self.total = off
+        self.index = {e[0]: e for e in self.entries}
+
+    def view(self, arena: torch.Tensor, name: str, true_shape=True):
+        _, off, stored, true = self.index[name]
+        n = 1
+        for s in stored:
+            n *= s
+        v = arena[off:off + n].view(stored)
+        if true_shape and stored != true:
+            v = v[:, :true[1]]
+        return v
+
+    def n_true_params(self):
+        t = 0
+        for _, _, _, true in self.entries:
+            n = 1
+            for s in true:
+                n *= s
+            t += n
+        return t
+
+    def init_(self, arena: torch.Tensor, generator: Optional[torch.Generator] = None):
+        """PyG / torch default initialisation: Glorot-uniform conv weights (a = sqrt(6/(in+out))), zero
+        conv bias, BN weight 1 / bias 0, nn.Linear default U(+-1/sqrt(fan_in)) for weight and bias."""
+        cpu = torch.zeros(self.total, dtype=torch.float32)
+        for name, off, stored, true in self.entries:
+            n = 1
+            for s in stored:
+                n *= s
+            v = cpu[off:off + n].view(stored)
+            if name.endswith("lin.weight"):
+                a = math.sqrt(6.0 / (true[0] + true[1]))
+                v[:, :true[1]].copy_(torch.empty(true).uniform_(-a, a, generator=generator))
+            elif name.startswith("bn") and name.endswith("weight"):
+                v.fill_(1.0)
+            elif name.startswith("linear"):
+                fan_in = 32 if name.startswith("linear1") else 16
+                b = 1.0 / math.sqrt(fan_in)
+                v.copy_(torch.empty(stored).uniform_(-b, b, generator=generator))
+        with torch.no_grad():
+            arena.copy_(cpu.to(arena.device))
+
+
+class GcnEngine:
+    """Forward/backward of one net over a fixed graph.  Holds activations and scratch; parameters and
+    gradients live in caller-owned flat arenas laid out by :class:`ArenaLayout`."""
+
+    def __init__(self, graph: ops.Graph, widths: List[int], kind: int, x0: torch.Tensor,
+                 x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None):
+        self.g = graph
+        self.kind = kind
+        self.layout = ArenaLayout(widths)
+        self.comm = comm or NoComm()
+        self.n_rows, self.n_cols = graph.n_rows, graph.n_cols
+        self.n_total = float(n_total if n_total is not None else graph.n_rows)
+        dev = x0.device
+        self.device = dev
+        L = self.layout
+        # static input, padded to a multiple of 4 channels (z2 has 7 columns)
+        assert x0.shape[0] >= self.n_cols and x0.shape[1] == L.cin[0]
+        self.x0 = torch.zeros((self.n_cols, L.cin_p[0]), dtype=torch.float32, device=dev)
+        self.x0[:, :L.cin[0]] = x0[:self.n_cols].to(torch.float32)
+        self.x_pos = None if x_pos is None else x_pos[:self.n_rows].contiguous().to(torch.float32)
+        self.agg_first = [L.cin_p[l] < L.cout[l] for l in range(12)]
+        cmax = max(L.cout)
+        nc = self.n_cols
+
+        def buf(c):
+            return torch.empty((nc, c), dtype=torch.float32, device=dev)
+
+        self.Y = [buf(L.cout[l]) for l in range(12)]                   # conv outputs (pre-BN), saved
+        self.P = [buf(L.cin_p[l]) if self.agg_first[l] else None for l in range(12)]
+        self._flat = [torch.empty(nc * cmax, dtype=torch.float32, device=dev) for _ in range(3)]
+        self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
+        self.c10 = torch.empty((2, cmax), dtype=torch.float32, device=dev)
+        self.sums = torch.empty(2 * cmax, dtype=torch.float64, device=dev)
+        self.running = [torch.zeros((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
+        for r in self.running:
+            r[1].fill_(1.0)                                            # running_var starts at 1
+        self.num_batches_tracked = torch.zeros(12, dtype=torch.int64, device=dev)
+        self.out = torch.empty((self.n_rows, 3), dtype=torch.float32, device=dev)
+        self._p1_ready = False
+
+    def _work(self, i, c):
+        return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, params: torch.Tensor, update_running: bool = True) -> torch.Tensor:
+        L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        X, pro = self.x0, None
+        for l in range(12):
+            i = l + 1
+            W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
+            b = L.view(params, "conv%d.bias" % i)
+            Y = self.Y[l]
+            if self.agg_first[l]:
+                P = self.P[l]
+                if l > 0 or not self._p1_ready:
+                    if l > 0:
+                        comm.halo_exchange(X, n)
+                    ops.spmm(g, X, out=P[:n], pro=pro)
+                    self._p1_ready = True
+                ops.gemm_nt(P, W, out=Y, bias=b, n_rows=n)
+            else:
+                H = self._work(0, L.cout[l])
+                ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n)
+                comm.halo_exchange(H, n)
+                ops.spmm(g, H, out=Y[:n], bias=b)
+            ops.bn_stats(Y, sums=self.sums, n_rows=n)
+            comm.all_reduce_sum(self.sums[: 2 * L.cout[l]])
+            ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
+                           self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
+            X, pro = Y, (self.bn4[l][0], self.bn4[l][1])
+        if update_running:
+            self.num_batches_tracked += 1
+        ops.head_fwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
+                     L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, self.x_pos,
+                     self.out, n_rows=n)
+        return self.out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+        """Overwrites ``grads`` (same layout as ``params``) with d loss / d params for the last forward."""
+        L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        dZ = self._work(1, 32)
+        ops.head_bwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
+                     L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, dout.contiguous(), dZ,
+                     L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
+                     L.view(grads, "linear2.weight"), L.view(grads, "linear2.bias"), n_rows=n)
+        cur = 1                                   # index of the work buffer holding dZ
+        for l in range(11, -1, -1):
+            i = l + 1
+            co, ci = L.cout[l], L.cin_p[l]
+            W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
+            dW = L.view(grads, "conv%d.lin.weight" % i, true_shape=False)
+            Y = self.Y[l]
+            ops.bn_bwd_reduce(dZ, Y, self.bn4[l], sums2=self.sums, n_rows=n)
+            comm.all_reduce_sum(self.sums[: 2 * co])
+            ops.bn_bwd_prepare(self.sums, self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % i),
+                               L.view(grads, "bn%d.bias" % i), self.c10[:, :co])
+            others = [k for k in range(3) if k != cur]
+            dY = self._work(others[0], co)
+            ops.bn_bwd_apply(dZ, Y, self.bn4[l], self.c10[:, :co], dY, self.sums, n_rows=n)
+            ops.f64_to_f32(self.sums[:co], L.view(grads, "conv%d.bias" % i))
+            if l > 0:
+                Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
+            else:
+                Xp, pro = self.x0, None
+            if self.agg_first[l]:
+                ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n)
+                if l > 0:
+                    dP = self._work(cur, ci)                    # dZ is dead once dY exists
+                    ops.gemm_nn(dY, W, out=dP, n_rows=n)
+                    comm.halo_exchange(dP, n)
+                    dZ = self._work(others[1], ci)
+                    ops.spmm(g, dP, out=dZ[:n])
+                    cur = others[1]
+            else:
+                comm.halo_exchange(dY, n)
+                dH = self._work(cur, co)
+                ops.spmm(g, dY, out=dH[:n])
+                ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n)
+                if l > 0:
+                    dZ = self._work(others[1], ci)
+                    ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+                    cur = others[1]
+        return grads

@@ -1,0 +1,396 @@
+"""Training losses on the HIP path -- same call signatures as ``util/loss.py`` of the reference.
+
+    pos_rec_loss(pred_pos, real_pos, ltype="rmse")            util/loss.py:16    float64 result
+    mesh_laplacian_loss(pred_pos, mesh, ltype="rmse")         util/loss.py:37
+    norm_rec_loss(pred_norm, real_norm, ltype="l1mae")        util/loss.py:55    float64 result
+    fn_bnf_loss(pos, fn, mesh, ltype="l1mae", loop=5)         util/loss.py:86    -> (loss, new_fn)
+    pos_norm_loss(pos, norm, mesh, ltype="mae")               util/loss.py:140
+    mad(norm1, norm2)                                         util/loss.py:261   float64 numpy
+
+Each is a ``torch.autograd.Function`` over ``ddmp_loss_*`` kernels (analytic gradients, gather form).
+Only the ``ltype`` each driver actually uses (``main.py:94-104``) is implemented on the device; another
+*valid* reference ltype raises ``NotImplementedError``; an unknown one follows the reference's error
+convention (prints ``[ERROR]: ltype error`` and exits, ``util/loss.py:32-34``).
+
+``mesh`` may be our :class:`mesh.Mesh` or any object with the reference's attributes ``vs``, ``faces``,
+``edges``, ``f2f``; index tables are converted to int32 device arrays once per mesh and cached on it
+(the reference re-uploads them on every call, ``util/loss.py:20,39-40,60,96``).
+
+:class:`LossEngine` is the fused form used by :mod:`trainer`: all five forwards, one finalize kernel that
+also produces the gradient coefficients on the device, and the two gradient kernels -- no host sync.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _p, _stream
+
+_P = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S5": 4, "SIG": 5}
+
+
+def _ltype_error():
+    print("[ERROR]: ltype error")
+    exit()
+
+
+def _ltype(ltype, ours, valid):
+    if ltype == ours:
+        return
+    if ltype in valid:
+        raise NotImplementedError("ltype=%r is valid in the reference but is not on the training hot path; "
+                                  "only %r runs on the device" % (ltype, ours))
+    _ltype_error()
+
+
+# ------------------------------------------------------------------------------------ mesh tables
+class MeshTables:
+    """int32 device copies of the connectivity the loss kernels read."""
+
+    def __init__(self, mesh, device):
+        faces = np.ascontiguousarray(mesh.faces, dtype=np.int64)
+        V, F = len(mesh.vs), len(faces)
+        self.V, self.F = V, F
+        e = np.asarray(mesh.edges, dtype=np.int64)
+        src = np.concatenate([e[:, 0], e[:, 1]])
+        dst = np.concatenate([e[:, 1], e[:, 0]])
+        order = np.argsort(src, kind="stable")
+        vv_ptr = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(np.bincount(src, minlength=V), out=vv_ptr[1:])
+        flat = faces.reshape(-1)
+        corner = np.argsort(flat, kind="stable")                 # entries 3*f + k grouped by vertex
+        vf_ptr = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(np.bincount(flat, minlength=V), out=vf_ptr[1:])
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+        self.faces = dev(faces)
+        self.f2f = dev(mesh.f2f)
+        self.vv_ptr, self.vv_idx = dev(vv_ptr), dev(dst[order])
+        self.vf_ptr, self.vf_corner = dev(vf_ptr), dev(corner)
+        self.device = device
+
+
+def tables_for(mesh, device) -> MeshTables:
+    cache = mesh.__dict__.setdefault("_ddmp_tables", {})
+    key = str(device)
+    t = cache.get(key)
+    if t is None or t.F != len(mesh.faces) or t.V != len(mesh.vs):
+        t = MeshTables(mesh, device)
+        cache[key] = t
+    return t
+
+
+_f64_cache = {}
+
+
+def _target(arr, device):
+    """float64 device copy of a numpy target (n_mesh.vs / n_mesh.fn), cached on the array identity."""
+    if isinstance(arr, torch.Tensor):
+        return arr.to(device=device, dtype=torch.float64).contiguous()
+    a = np.asarray(arr)
+    key = (a.__array_interface__["data"][0], a.shape, str(a.dtype), str(device))
+    hit = _f64_cache.get(key)
+    if hit is not None and hit[0] is arr:
+        return hit[1]
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    if len(_f64_cache) > 32:
+        _f64_cache.clear()
+    _f64_cache[key] = (arr, t)
+    return t
+
+
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.DdmpError("%s must be a CUDA tensor (HIP path, no CPU fallback)" % name)
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Scratch:
+    """Per-(V,F,loop) buffers of the loss kernels."""
+
+    def __init__(self, V, F, loop, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.V, self.F, self.loop = V, F, loop
+        self.resid = torch.empty((V, 3), **f)
+        self.fc = torch.empty((F, 3), **f)
+        self.fa = torch.empty((F,), **f)
+        self.pn_coef = torch.empty((F, 3), **f)
+        self.pn_dn = torch.empty((F, 3), **f)
+        self.fcd = torch.empty((F, 3), **f)
+        self.bnf_n = torch.empty((loop + 1, F, 3), **f)
+        self.bnf_A = torch.empty((max(loop, 1), F, 3), **f)
+        self.G0 = torch.empty((F, 3), **f)
+        self.scr = torch.empty((2, F, 3), **f)
+        self.partials = torch.zeros(_lib.lib().ddmp_loss_partials_bytes() // 8, dtype=torch.float64, device=device)
+        self.lossbuf = torch.zeros(12, dtype=torch.float64, device=device)
+        self.dpos = torch.empty((V, 3), **f)
+        self.dnorm = torch.empty((F, 3), **f)
+        self.zero_v64 = None
+        self.zero_f64 = None
+
+    def sum(self, which):
+        return self.partials.view(6, -1)[_P[which]].sum()
+
+
+# kernels ------------------------------------------------------------------------------------------
+def _vertex_fwd(tb, pos, real, s):
+    check(_lib.lib().ddmp_loss_vertex_fwd(tb.V, _p(pos), _p(real), _p(tb.vv_ptr), _p(tb.vv_idx), _p(s.resid),
+                                          _p(s.partials), _stream()), "ddmp_loss_vertex_fwd")
+
+
+def _face_fwd(tb, pos, norm, real_n, s):
+    check(_lib.lib().ddmp_loss_face_fwd(tb.F, _p(pos), _p(norm), _p(real_n), _p(tb.faces), _p(s.fc), _p(s.fa),
+                                        _p(s.pn_coef), _p(s.pn_dn), _p(s.partials), _stream()), "ddmp_loss_face_fwd")
+
+
+def _bnf_fwd(tb, norm, loop, s):
+    check(_lib.lib().ddmp_loss_bnf_fwd(tb.F, _p(norm), _p(tb.f2f), _p(s.fc), _p(s.fa), loop, _p(s.fcd), _p(s.bnf_n),
+                                       _p(s.bnf_A), _p(s.partials), _stream()), "ddmp_loss_bnf_fwd")
+
+
+def _bnf_bwd(tb, loop, coef, s):
+    check(_lib.lib().ddmp_loss_bnf_bwd(tb.F, _p(tb.f2f), _p(s.fa), _p(s.fcd), loop, _p(s.bnf_n), _p(s.bnf_A),
+                                       _p(s.partials), _p(coef), _p(s.G0), _p(s.scr), _stream()), "ddmp_loss_bnf_bwd")
+
+
+def _face_bwd(tb, norm, real_n, coef, s, with_bnf, loop, out):
+    check(_lib.lib().ddmp_loss_face_bwd(tb.F, _p(norm), _p(real_n), _p(s.pn_dn), _p(s.G0) if with_bnf else None,
+                                        _p(s.bnf_n[loop]) if with_bnf else None, _p(coef), _p(out), _stream()),
+          "ddmp_loss_face_bwd")
+
+
+def _vertex_bwd(tb, pos, real, norm, coef, s, out):
+    check(_lib.lib().ddmp_loss_vertex_bwd(tb.V, _p(pos), _p(real), _p(s.resid), _p(tb.vv_ptr), _p(tb.vv_idx),
+                                          _p(tb.vf_ptr), _p(tb.vf_corner), _p(s.pn_coef), _p(norm), _p(coef), _p(out),
+                                          _stream()), "ddmp_loss_vertex_bwd")
+
+
+def _coef(device, idx, value):
+    c = torch.zeros(5, dtype=torch.float64, device=device)
+    c[idx] = value.to(torch.float64)
+    return c
+
+
+# ------------------------------------------------------------------------ reference-signature losses
+class _PosRec(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_pos, real, tb_like):
+        pos = _f32(pred_pos, "pred_pos")
+        V = pos.shape[0]
+        s = _Scratch(V, 1, 0, pos.device)
+        tb = tb_like
+        _vertex_fwd(tb, pos, real, s)
+        loss = torch.sqrt(s.sum("S1") / V + 1.0e-6)
+        ctx.save_for_backward(pos, real, loss)
+        ctx.tb, ctx.s = tb, s
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, real, loss = ctx.saved_tensors
+        tb, s = ctx.tb, ctx.s
+        coef = _coef(pos.device, 0, g / (tb.V * loss))
+        out = torch.empty_like(pos)
+        _vertex_bwd(tb, pos, real, pos, coef, s, out)
+        return out, None, None
+
+
+class _NoAdj:
+    """vertex tables with empty 1-rings (pos_rec_loss needs no mesh)."""
+
+    def __init__(self, V, device):
+        z = torch.zeros(V + 1, dtype=torch.int32, device=device)
+        self.V, self.F = V, 1
+        self.vv_ptr = self.vf_ptr = z
+        self.vv_idx = self.vf_corner = z
+
+
+def pos_rec_loss(pred_pos, real_pos, ltype="rmse"):
+    """reconstruction error for vertex positions (util/loss.py:16-35)."""
+    _ltype(ltype, "rmse", ("l1mae", "rmse"))
+    real = _target(real_pos, pred_pos.device)
+    return _PosRec.apply(pred_pos, real, _NoAdj(pred_pos.shape[0], pred_pos.device))
+
+
+class _Lap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_pos, tb, real):
+        pos = _f32(pred_pos, "pred_pos")
+        s = _Scratch(tb.V, 1, 0, pos.device)
+        _vertex_fwd(tb, pos, real, s)
+        loss = torch.sqrt((s.sum("S2") / tb.V).to(torch.float32) + 1.0e-12)
+        ctx.save_for_backward(pos, real, loss)
+        ctx.tb, ctx.s = tb, s
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, real, loss = ctx.saved_tensors
+        tb, s = ctx.tb, ctx.s
+        coef = _coef(pos.device, 1, g.to(torch.float64) / (tb.V * loss.to(torch.float64)))
+        out = torch.empty_like(pos)
+        _vertex_bwd(tb, pos, real, pos, coef, s, out)
+        return out, None, None
+
+
+def mesh_laplacian_loss(pred_pos, mesh, ltype="rmse"):
+    """simple laplacian for output meshes (util/loss.py:37-53)."""
+    _ltype(ltype, "rmse", ("mae", "rmse"))
+    tb = tables_for(mesh, pred_pos.device)
+    return _Lap.apply(pred_pos, tb, _target(mesh.vs, pred_pos.device))
+
+
+class _NormRec(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_norm, real):
+        nrm = _f32(pred_norm, "pred_norm")
+        F = nrm.shape[0]
+        s = _Scratch(1, F, 0, nrm.device)
+        tb = type("T", (), {})()
+        tb.F, tb.V = F, 1
+        tb.faces = torch.zeros((F, 3), dtype=torch.int32, device=nrm.device)
+        pos = torch.zeros((1, 3), dtype=torch.float32, device=nrm.device)
+        _face_fwd(tb, pos, nrm, real, s)
+        loss = s.sum("S3") / F
+        ctx.save_for_backward(nrm, real)
+        ctx.tb, ctx.s = tb, s
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        nrm, real = ctx.saved_tensors
+        tb, s = ctx.tb, ctx.s
+        coef = _coef(nrm.device, 2, g / tb.F)
+        out = torch.empty_like(nrm)
+        _face_bwd(tb, nrm, real, coef, s, False, 0, out)
+        return out, None
+
+
+def norm_rec_loss(pred_norm, real_norm, ltype="l1mae"):
+    """reconstruction loss for (vertex, face) normal (util/loss.py:55-84)."""
+    _ltype(ltype, "l1mae", ("l2mae", "l1mae", "l2rmse", "l1rmse", "cos"))
+    return _NormRec.apply(pred_norm, _target(real_norm, pred_norm.device))
+
+
+class _Bnf(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fn, pos, tb, loop, zero_real):
+        nrm = _f32(fn, "fn")
+        s = _Scratch(tb.V, tb.F, loop, nrm.device)
+        _face_fwd(tb, pos, nrm, zero_real, s)
+        _bnf_fwd(tb, nrm, loop, s)
+        loss = (s.sum("S4") / tb.F).to(torch.float32)
+        ctx.save_for_backward(nrm, zero_real)
+        ctx.tb, ctx.s, ctx.loop = tb, s, loop
+        new_fn = s.bnf_n[loop]
+        ctx.mark_non_differentiable(new_fn)
+        return loss, new_fn
+
+    @staticmethod
+    def backward(ctx, g, _g_newfn):
+        nrm, zero_real = ctx.saved_tensors
+        tb, s, loop = ctx.tb, ctx.s, ctx.loop
+        coef = _coef(nrm.device, 3, g.to(torch.float64) / tb.F)
+        _bnf_bwd(tb, loop, coef, s)
+        out = torch.empty_like(nrm)
+        _face_bwd(tb, nrm, zero_real, coef, s, True, loop, out)
+        return out, None, None, None, None
+
+
+def fn_bnf_loss(pos, fn, mesh, ltype="l1mae", loop=5):
+    """bilateral loss for face normal (util/loss.py:86-138); ``pos`` is treated as a constant."""
+    _ltype(ltype, "l1mae", ("mae", "l1mae", "rmse", "l1rmse"))
+    dev = fn.device
+    if isinstance(pos, np.ndarray):
+        pos = torch.from_numpy(pos).to(dev)
+    tb = tables_for(mesh, dev)
+    zero_real = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
+    return _Bnf.apply(fn, _f32(pos, "pos"), tb, int(loop), zero_real)
+
+
+class _PosNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos_in, norm_in, tb, zero_real_f, zero_real_v):
+        pos, nrm = _f32(pos_in, "pos"), _f32(norm_in, "norm")
+        s = _Scratch(tb.V, tb.F, 0, pos.device)
+        _face_fwd(tb, pos, nrm, zero_real_f, s)
+        loss = (s.sum("S5") / tb.V).to(torch.float32)
+        ctx.save_for_backward(pos, nrm, zero_real_f, zero_real_v)
+        ctx.tb, ctx.s = tb, s
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, nrm, zf, zv = ctx.saved_tensors
+        tb, s = ctx.tb, ctx.s
+        coef = _coef(pos.device, 4, g.to(torch.float64) / tb.V)
+        dnorm = torch.empty_like(nrm)
+        _face_bwd(tb, nrm, zf, coef, s, False, 0, dnorm)
+        dpos = torch.empty_like(pos)
+        _vertex_bwd(tb, pos, zv, nrm, coef, s, dpos)
+        return dpos, dnorm, None, None, None
+
+
+def pos_norm_loss(pos, norm, mesh, ltype="mae"):
+    """loss between vertex position and face normal (util/loss.py:140-160)."""
+    _ltype(ltype, "mae", ("mae", "rmse"))
+    dev = pos.device
+    tb = tables_for(mesh, dev)
+    zf = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
+    zv = torch.zeros((tb.V, 3), dtype=torch.float64, device=dev)
+    return _PosNorm.apply(pos, norm, tb, zf, zv)
+
+
+def mad(norm1, norm2):
+    """mean angular distance in degrees (util/loss.py:261-272), float64 numpy like the reference."""
+    if type(norm1) == torch.Tensor:
+        norm1 = norm1.to("cpu").detach().numpy().copy()
+    if type(norm2) == torch.Tensor:
+        norm2 = norm2.to("cpu").detach().numpy().copy()
+    inner = np.sum(norm1 * norm2, 1)
+    sad = np.rad2deg(np.arccos(np.clip(inner, -1.0, 1.0)))
+    return np.sum(sad) / len(sad)
+
+
+def angular_difference(norm1, norm2):
+    """util/loss.py:274-277."""
+    inner = np.sum(norm1 * norm2, 1)
+    return np.rad2deg(np.arccos(np.clip(inner, -1.0, 1.0)))
+
+
+# ------------------------------------------------------------------------------------ fused form
+class LossEngine:
+    """All five losses + gradients with device-side scalars (main.py:94-106 in one go)."""
+
+    def __init__(self, mesh, device, bnfloop=1, k=(3.0, 4.0, 4.0, 4.0, 1.0)):
+        self.tb = tables_for(mesh, device)
+        self.real_pos = _target(mesh.vs, device)
+        self.real_norm = _target(mesh.fn, device)
+        self.loop = int(bnfloop)
+        self.k = (ctypes.c_double * 5)(*[float(x) for x in k])
+        self.k_list = [float(x) for x in k]
+        self.s = _Scratch(self.tb.V, self.tb.F, self.loop, device)
+
+    def forward_backward(self, pos, norm, gate4: float):
+        """-> (lossbuf [12] float64 device, dpos [V,3], dnorm [F,3]).  ``gate4`` = 0.0 while epoch <= 100
+        (main.py:101-102).  The BNF value is always computed; its backward is skipped when k4*gate4 == 0
+        (the reference back-propagates a zero there)."""
+        tb, s, loop = self.tb, self.s, self.loop
+        _vertex_fwd(tb, pos, self.real_pos, s)
+        _face_fwd(tb, pos, norm, self.real_norm, s)
+        _bnf_fwd(tb, norm, loop, s)
+        check(_lib.lib().ddmp_loss_finalize(_p(s.partials), tb.V, tb.F, self.k, float(gate4), _p(s.lossbuf), _stream()),
+              "ddmp_loss_finalize")
+        coef = s.lossbuf[6:11]
+        with_bnf = (self.k_list[3] * gate4) != 0.0
+        if with_bnf:
+            _bnf_bwd(tb, loop, coef, s)
+        _face_bwd(tb, norm, self.real_norm, coef, s, with_bnf, loop, s.dnorm)
+        _vertex_bwd(tb, pos, self.real_pos, norm, coef, s, s.dpos)
+        return s.lossbuf, s.dpos, s.dnorm

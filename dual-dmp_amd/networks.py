@@ -1,0 +1,206 @@
+"""PosNet / NormalNet on the HIP path (host-side mirror of ``util/networks.py`` of the reference).
+
+Two interchangeable forms, both taking the reference's ``Dataset`` object (fields ``z1``, ``z2``,
+``x_pos``, ``edge_index``, ``face_index``) and returning ``pos`` [V,3] / ``norm`` [F,3]:
+
+``PosNet(device)`` / ``NormalNet(device)``                              (``fused=True``, default)
+    the whole trunk + head runs through :class:`engine.GcnEngine` (prologue-fused kernels, only conv
+    outputs stored).  All parameters live in one flat float32 ``arena`` parameter, so
+    ``torch.optim.Adam(net.parameters())`` and ``clip_grad_norm_(net.parameters(), ..)`` of the
+    reference's loop (main.py:54-55,108-110) act on a single tensor; ``state_dict()`` /
+    ``load_state_dict()`` speak the reference's names (``conv1.lin.weight`` ... ``linear2.bias``,
+    ``bn1.running_mean`` ...).
+
+``PosNet(device, fused=False)`` / ``NormalNet(device, fused=False)``
+    the reference's module structure verbatim -- 12 x (``GCNConv`` -> ``nn.BatchNorm1d`` ->
+    ``nn.LeakyReLU``) + two ``nn.Linear`` -- with our drop-in :class:`nn_ops.GCNConv` standing where
+    ``torch_geometric.nn.GCNConv`` stands in ``util/networks.py:4``.
+
+The reference's unused ``torch.randn(V,3)*1e-5`` draw (``util/networks.py:50``) is dropped: it only
+advances the RNG.  ``z1``/``z2`` carry ``requires_grad=True`` in the reference but are never
+optimised; their gradient is not computed here.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .engine import ArenaLayout, GcnEngine, NORM_WIDTHS, POS_WIDTHS
+from .nn_ops import GCNConv
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, arena, net):
+        eng = net._engine
+        out = eng.forward(arena.detach(), update_running=net.training)
+        ctx.net = net
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        net = ctx.net
+        eng = net._engine
+        eng.backward(net.arena.detach(), net._grad_arena, dout)
+        if eng.comm.world_size > 1:
+            net._reduce_grads()
+        return net._grad_arena.clone(), None
+
+
+class _FusedNet(nn.Module):
+    _widths = None
+    _kind = 0
+
+    def __init__(self, device, comm=None):
+        super().__init__()
+        self.device = torch.device(device)
+        self.layout = ArenaLayout(self._widths)
+        self.arena = nn.Parameter(torch.zeros(self.layout.total, dtype=torch.float32, device=self.device))
+        self.layout.init_(self.arena.data)
+        self._grad_arena = torch.zeros_like(self.arena.data)
+        self._engine = None
+        self._engine_key = None
+        self.comm = comm
+
+    # ------------------------------------------------------------ reference-named access
+    def named_views(self, grads=False):
+        src = self._grad_arena if grads else self.arena.data
+        return OrderedDict((name, self.layout.view(src, name)) for name, *_ in self.layout.entries)
+
+    def num_parameters(self):
+        return self.layout.n_true_params()
+
+    def state_dict(self, *args, **kwargs):
+        sd = OrderedDict()
+        for name, v in self.named_views().items():
+            sd[name] = v.detach().clone()
+        eng = self._engine
+        for l in range(12):
+            if eng is not None:
+                sd["bn%d.running_mean" % (l + 1)] = eng.running[l][0].clone()
+                sd["bn%d.running_var" % (l + 1)] = eng.running[l][1].clone()
+                sd["bn%d.num_batches_tracked" % (l + 1)] = eng.num_batches_tracked[l].clone()
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        views = self.named_views()
+        with torch.no_grad():
+            for name, v in views.items():
+                if name in sd:
+                    v.copy_(sd[name].to(v.device, torch.float32))
+                elif strict:
+                    raise KeyError("missing key %s" % name)
+        self._pending_running = {k: v for k, v in sd.items() if "running_" in k}
+        return self
+
+    # ------------------------------------------------------------ engine plumbing
+    def _inputs(self, data):
+        raise NotImplementedError
+
+    def _get_engine(self, data):
+        x0, x_pos, edge_index = self._inputs(data)
+        key = (x0.data_ptr(), edge_index.data_ptr(), tuple(edge_index.shape), x0.shape[0])
+        if self._engine is None or self._engine_key != key:
+            dev = self.device
+            graph = getattr(data, "_ddmp_graph_%d" % self._kind, None)
+            if graph is None:
+                graph = ops.graph_for(edge_index.to(dev), x0.shape[0])
+            self._engine = GcnEngine(graph, self._widths, self._kind, x0.detach().to(dev),
+                                     None if x_pos is None else x_pos.to(dev), comm=self.comm,
+                                     n_total=getattr(data, "_ddmp_n_total_%d" % self._kind, None))
+            self._engine_key = key
+            pend = getattr(self, "_pending_running", None)
+            if pend:
+                for l in range(12):
+                    for j, nm in enumerate(("running_mean", "running_var")):
+                        k = "bn%d.%s" % (l + 1, nm)
+                        if k in pend:
+                            self._engine.running[l][j].copy_(pend[k].to(dev))
+        return self._engine
+
+    def forward(self, data):
+        self._get_engine(data)
+        return _EngineFn.apply(self.arena, self)
+
+    def _reduce_grads(self):
+        """Multi-device: weight gradients are sums over the row shards; BatchNorm weight/bias gradients
+        were computed from already all-reduced column sums, so they are identical on every rank."""
+        comm = self._engine.comm
+        g = self._grad_arena
+        keep = [(n, self.layout.view(g, n).clone()) for n, *_ in self.layout.entries if n.startswith("bn")]
+        comm.all_reduce_sum(g)
+        for n, v in keep:
+            self.layout.view(g, n).copy_(v)
+
+
+class PosNetFused(_FusedNet):
+    """util/networks.py:8-67."""
+    _widths = POS_WIDTHS
+    _kind = 0
+
+    def _inputs(self, data):
+        return data.z1, data.x_pos, data.edge_index
+
+
+class NormalNetFused(_FusedNet):
+    """util/networks.py:69-130."""
+    _widths = NORM_WIDTHS
+    _kind = 1
+
+    def _inputs(self, data):
+        return data.z2, None, data.face_index
+
+
+# -------------------------------------------------------------------------------- operator-level form
+class _ModularNet(nn.Module):
+    _widths = None
+
+    def __init__(self, device):
+        super().__init__()
+        self.device = torch.device(device)
+        h = self._widths
+        for i in range(12):
+            setattr(self, "conv%d" % (i + 1), GCNConv(h[i], h[i + 1]))
+        self.linear1 = nn.Linear(h[12], h[13])
+        self.linear2 = nn.Linear(h[13], h[14])
+        for i in range(12):
+            setattr(self, "bn%d" % (i + 1), nn.BatchNorm1d(h[i + 1]))
+        self.l_relu = nn.LeakyReLU()
+        self.to(self.device)
+
+    def _trunk(self, x, edge_index):
+        for i in range(1, 13):
+            x = self.l_relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(x, edge_index)))
+        return x
+
+
+class PosNetModular(_ModularNet):
+    _widths = POS_WIDTHS
+
+    def forward(self, data):
+        z1, x_pos, edge_index = data.z1.to(self.device), data.x_pos.to(self.device), data.edge_index.to(self.device)
+        dx = self._trunk(z1, edge_index)
+        dx = self.linear2(self.l_relu(self.linear1(dx)))
+        return x_pos + dx
+
+
+class NormalNetModular(_ModularNet):
+    _widths = NORM_WIDTHS
+
+    def forward(self, data):
+        z2, edge_index = data.z2.to(self.device), data.face_index.to(self.device)
+        dx = self._trunk(z2, edge_index)
+        dx = torch.tanh(self.linear2(self.l_relu(self.linear1(dx))))
+        dx_norm = torch.reciprocal(torch.norm(dx, dim=1, keepdim=True).expand(-1, 3) + 1.0e-12)
+        return torch.mul(dx, dx_norm)
+
+
+def PosNet(device, fused=True, **kw):
+    return PosNetFused(device, **kw) if fused else PosNetModular(device)
+
+
+def NormalNet(device, fused=True, **kw):
+    return NormalNetFused(device, **kw) if fused else NormalNetModular(device)

@@ -1,0 +1,339 @@
+"""Tensor-level wrappers over the C ABI (``include/ddmp_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every wrapper passes raw device
+pointers + sizes to ``libddmp_hip.so`` and enqueues on ``torch.cuda.current_stream()``.
+No wrapper has a CPU path: a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DdmpError, check
+
+SLOPE = 0.01        # nn.LeakyReLU() default, util/networks.py:44
+BN_EPS = 1e-5       # nn.BatchNorm1d defaults
+BN_MOMENTUM = 0.1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DdmpError("%s must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise DdmpError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _mat(t, name="matrix"):
+    """2-D float32 CUDA tensor with unit inner stride -> (tensor, leading dimension)."""
+    _chk(t, torch.float32, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise DdmpError("%s must be 2-D with contiguous rows" % name)
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+class Workspace:
+    """Grow-only scratch buffer (one per device) for split-K partials and column reductions."""
+
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes: int, device) -> torch.Tensor:
+        key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+# ---------------------------------------------------------------------------------------- graph
+class Graph:
+    """CSR of A + I with D^-1/2 on the device (``ddmp_graph``).  Built once per edge_index
+    (the reference's GCNConv re-normalises on every call, cached=False)."""
+
+    def __init__(self, handle, n_rows, n_cols, nnz):
+        self._h = handle
+        self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
+        self._fin = weakref.finalize(self, _lib.lib().ddmp_graph_destroy, handle)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, num_nodes: int) -> "Graph":
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise DdmpError("edge_index must be a [2, nnz] int64 tensor")
+        ei = edge_index.contiguous()
+        h = ctypes.c_void_p()
+        st = _lib.lib().ddmp_graph_create(int(num_nodes), int(ei.shape[1]), _p(ei), 1 if ei.is_cuda else 0,
+                                          ctypes.byref(h))
+        check(st, "ddmp_graph_create")
+        return cls(h, int(num_nodes), int(num_nodes), int(ei.shape[1]) + int(num_nodes))
+
+    @classmethod
+    def from_csr_host(cls, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, n_cols: int) -> "Graph":
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        dinv = np.ascontiguousarray(dinv, dtype=np.float32)
+        n_rows = len(rowptr) - 1
+        h = ctypes.c_void_p()
+        st = _lib.lib().ddmp_graph_create_csr_host(n_rows, int(n_cols), rowptr.ctypes.data, col.ctypes.data,
+                                                   dinv.ctypes.data, ctypes.byref(h))
+        check(st, "ddmp_graph_create_csr_host")
+        return cls(h, n_rows, int(n_cols), int(rowptr[-1]))
+
+
+_graph_cache = {}
+
+
+def graph_for(edge_index: torch.Tensor, num_nodes: int) -> Graph:
+    """Cache keyed on the edge_index storage + version (static mesh graph)."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
+           str(edge_index.device))
+    g = _graph_cache.get(key)
+    if g is None:
+        if len(_graph_cache) > 16:
+            _graph_cache.clear()
+        g = Graph.from_edge_index(edge_index, num_nodes)
+        _graph_cache[key] = g
+    return g
+
+
+def csr_build_host(edge_index: np.ndarray, num_nodes: int):
+    """Host CSR (no GPU needed): -> rowptr int32[n+1], col int32[nnz'], dinv f32[n]."""
+    ei = np.ascontiguousarray(edge_index, dtype=np.int64)
+    nnz = ei.shape[1]
+    rowptr = np.zeros(num_nodes + 1, np.int32)
+    col = np.zeros(nnz + num_nodes, np.int32)
+    dinv = np.zeros(num_nodes, np.float32)
+    cap = ctypes.c_int64(nnz + num_nodes)
+    st = _lib.lib().ddmp_csr_build_host(num_nodes, nnz, ei.ctypes.data, rowptr.ctypes.data, col.ctypes.data,
+                                        dinv.ctypes.data, ctypes.byref(cap))
+    check(st, "ddmp_csr_build_host")
+    return rowptr, col[:cap.value].copy(), dinv
+
+
+def bfs_order_host(rowptr: np.ndarray, col: np.ndarray) -> np.ndarray:
+    n = len(rowptr) - 1
+    order = np.zeros(n, np.int32)
+    st = _lib.lib().ddmp_csr_bfs_order_host(n, rowptr.ctypes.data, col.ctypes.data, order.ctypes.data)
+    check(st, "ddmp_csr_bfs_order_host")
+    return order
+
+
+# ---------------------------------------------------------------------------------------- kernels
+def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
+    """out[i] = dinv_i * sum_j dinv_j f(x[j]) (+bias); x has g.n_cols rows, out g.n_rows rows."""
+    x, ldx = _mat(x, "x")
+    if x.shape[0] < g.n_cols:
+        raise DdmpError("x has %d rows, graph references %d nodes" % (x.shape[0], g.n_cols))
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((g.n_rows, C), dtype=torch.float32, device=x.device)
+    out, ldy = _mat(out, "out")
+    ps, psh = (None, None) if pro is None else pro
+    st = _lib.lib().ddmp_spmm_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope, _stream())
+    check(st, "ddmp_spmm_f32")
+    return out
+
+
+def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
+    """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
+    a, lda = _mat(a, "a")
+    w, ldw = _mat(w, "w")
+    n = a.shape[0] if n_rows is None else n_rows
+    K, M = a.shape[1], w.shape[0]
+    if w.shape[1] != K:
+        raise DdmpError("gemm_nt: inner dimensions differ (%d vs %d)" % (K, w.shape[1]))
+    if out is None:
+        out = torch.empty((n, M), dtype=torch.float32, device=a.device)
+    out, ldy = _mat(out, "out")
+    ps, psh = (None, None) if pro is None else pro
+    st = _lib.lib().ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
+                                     _stream())
+    check(st, "ddmp_gemm_nt_f32")
+    return out
+
+
+def gemm_nn(a, w, out=None, n_rows=None):
+    """out[n,K] = a[n,M] @ w[M,K]."""
+    a, lda = _mat(a, "a")
+    w, ldw = _mat(w, "w")
+    n = a.shape[0] if n_rows is None else n_rows
+    M, K = w.shape
+    if a.shape[1] != M:
+        raise DdmpError("gemm_nn: inner dimensions differ")
+    if out is None:
+        out = torch.empty((n, K), dtype=torch.float32, device=a.device)
+    out, ldy = _mat(out, "out")
+    st = _lib.lib().ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _stream())
+    check(st, "ddmp_gemm_nn_f32")
+    return out
+
+
+def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
+    """out[M,K] = g[n,M]^T @ f(z[n,K])  (weight gradient)."""
+    g, ldg = _mat(g, "g")
+    z, ldz = _mat(z, "z")
+    n = g.shape[0] if n_rows is None else n_rows
+    M, K = g.shape[1], z.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=g.device)
+    out, ldo = _mat(out, "out")
+    L = _lib.lib()
+    need = L.ddmp_gemm_tn_workspace_bytes(n, M, K)
+    ws = Workspace.get(need, g.device)
+    ps, psh = (None, None) if pro is None else pro
+    st = L.ddmp_gemm_tn_f32(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _p(ps), _p(psh), slope, _p(ws),
+                            ws.numel(), _stream())
+    check(st, "ddmp_gemm_tn_f32")
+    return out
+
+
+def _colws(n, C, device):
+    need = _lib.lib().ddmp_colreduce_workspace_bytes(n, C)
+    if need == 0:
+        raise DdmpError("column reduction: unsupported width %d (power of two in [8,1024])" % C)
+    return Workspace.get(need, device)
+
+
+def bn_stats(y, sums=None, n_rows=None):
+    """-> float64 [2C] = (column sums, column sums of squares) of y[:n_rows]."""
+    y, ldy = _mat(y, "y")
+    n = y.shape[0] if n_rows is None else n_rows
+    C = y.shape[1]
+    if sums is None:
+        sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
+    ws = _colws(n, C, y.device)
+    st = _lib.lib().ddmp_bn_stats_f32(_p(y), ldy, n, C, _p(sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_bn_stats_f32")
+    return sums
+
+
+def bn_prepare(sums, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """out4: float32 [4,C] rows = scale, shift, mean, rstd (written)."""
+    C = gamma.numel()
+    rm, rv = (None, None) if running is None else running
+    st = _lib.lib().ddmp_bn_prepare_f32(_p(sums), float(n_total), C, _p(gamma), _p(beta), eps, momentum,
+                                        _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3]), _p(rm), _p(rv), _stream())
+    check(st, "ddmp_bn_prepare_f32")
+    return out4
+
+
+def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):
+    y, ldy = _mat(y, "y")
+    if out is None:
+        out = torch.empty_like(y)
+    out, ldz = _mat(out, "out")
+    st = _lib.lib().ddmp_bn_lrelu_apply_f32(_p(y), ldy, _p(out), ldz, y.shape[0], y.shape[1], _p(scale), _p(shift),
+                                            slope, _stream())
+    check(st, "ddmp_bn_lrelu_apply_f32")
+    return out
+
+
+def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None):
+    dz, lddz = _mat(dz, "dz")
+    y, ldy = _mat(y, "y")
+    n = y.shape[0] if n_rows is None else n_rows
+    C = y.shape[1]
+    if sums2 is None:
+        sums2 = torch.empty(2 * C, dtype=torch.float64, device=y.device)
+    ws = _colws(n, C, y.device)
+    st = _lib.lib().ddmp_bn_bwd_reduce_f32(_p(dz), lddz, _p(y), ldy, n, C, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
+                                           _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_bn_bwd_reduce_f32")
+    return sums2
+
+
+def bn_bwd_prepare(sums2, n_total, bn4, dgamma, dbeta, c10):
+    """c10: float32 [2,C] rows = c1, c0 (written)."""
+    C = dgamma.numel()
+    st = _lib.lib().ddmp_bn_bwd_prepare_f32(_p(sums2), float(n_total), C, _p(bn4[0]), _p(bn4[2]), _p(bn4[3]),
+                                            _p(dgamma), _p(dbeta), _p(c10[0]), _p(c10[1]), _stream())
+    check(st, "ddmp_bn_bwd_prepare_f32")
+
+
+def bn_bwd_apply(dz, y, bn4, c10, dy, dbias_sums, slope=SLOPE, n_rows=None):
+    dz, lddz = _mat(dz, "dz")
+    y, ldy = _mat(y, "y")
+    dy, lddy = _mat(dy, "dy")
+    n = y.shape[0] if n_rows is None else n_rows
+    C = y.shape[1]
+    ws = _colws(n, C, y.device)
+    st = _lib.lib().ddmp_bn_bwd_apply_f32(_p(dz), lddz, _p(y), ldy, _p(dy), lddy, n, C, _p(bn4[0]), _p(bn4[1]),
+                                          _p(c10[0]), _p(c10[1]), slope, _p(dbias_sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_bn_bwd_apply_f32")
+    return dy
+
+
+def colsum(x, sums=None, n_rows=None):
+    x, ldx = _mat(x, "x")
+    n = x.shape[0] if n_rows is None else n_rows
+    C = x.shape[1]
+    if sums is None:
+        sums = torch.empty(C, dtype=torch.float64, device=x.device)
+    ws = _colws(n, C, x.device)
+    st = _lib.lib().ddmp_colsum_f32(_p(x), ldx, n, C, _p(sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_colsum_f32")
+    return sums
+
+
+def f64_to_f32(src, dst):
+    st = _lib.lib().ddmp_f64_to_f32(_p(src), _p(dst), src.numel(), _stream())
+    check(st, "ddmp_f64_to_f32")
+    return dst
+
+
+def head_fwd(y, bn4, W1, b1, W2, b2, kind, x_pos, out, slope=SLOPE, n_rows=None):
+    y, ldy = _mat(y, "y")
+    n = y.shape[0] if n_rows is None else n_rows
+    st = _lib.lib().ddmp_head_fwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2),
+                                      kind, _p(x_pos), _p(out), _stream())
+    check(st, "ddmp_head_fwd_f32")
+    return out
+
+
+def head_bwd(y, bn4, W1, b1, W2, b2, kind, dout, dz, dW1, db1, dW2, db2, slope=SLOPE, n_rows=None):
+    y, ldy = _mat(y, "y")
+    dz, lddz = _mat(dz, "dz")
+    n = y.shape[0] if n_rows is None else n_rows
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_head_bwd_workspace_bytes(n), y.device)
+    st = L.ddmp_head_bwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2), kind,
+                             _p(dout), _p(dz), lddz, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_head_bwd_f32")
+
+
+def grad_sumsq(g, out=None):
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=g.device)
+    ws = Workspace.get(L.ddmp_sumsq_workspace_bytes(), g.device)
+    st = L.ddmp_grad_sumsq_f32(_p(g), g.numel(), _p(out), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_grad_sumsq_f32")
+    return out
+
+
+def grad_clip_(g, sumsq, max_norm):
+    st = _lib.lib().ddmp_grad_clip_f32(_p(g), g.numel(), _p(sumsq), float(max_norm), _stream())
+    check(st, "ddmp_grad_clip_f32")
+
+
+def adam_step_(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, clip_sumsq=None, max_norm=0.0):
+    st = _lib.lib().ddmp_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), betas[0], betas[1], eps,
+                                       int(step), _p(clip_sumsq), float(max_norm), _stream())
+    check(st, "ddmp_adam_step_f32")

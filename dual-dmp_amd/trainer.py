@@ -1,0 +1,63 @@
+"""One training iteration of Dual-DMP on the HIP path (``main.py:88-110`` == ``main4real.py:53-75``).
+
+    zero_grad; pos = posnet(data); norm = normnet(data)
+    loss = k1*pos_rec + k2*laplacian + k3*norm_rec + k4*[epoch>100]*bnf + k5*pos_norm
+    loss.backward(); clip_grad_norm_(normnet, grad_crip); Adam.step() x2
+
+:class:`FusedTrainer` runs exactly that sequence with everything device-resident and no autograd
+graph: two engine forwards, :class:`loss.LossEngine` (values + analytic gradients + device-side
+coefficients), two engine backwards, one global-norm reduction and two fused clip+Adam updates over the
+flat arenas.  ``step()`` returns the loss as a 0-dim float64 device tensor; calling ``.item()`` on it is
+the reference's only per-step sync (``main.py:113``).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .loss import LossEngine
+
+
+class FusedTrainer:
+    def __init__(self, posnet, normnet, dataset, n_mesh, pos_lr=0.01, norm_lr=0.01, k=(3.0, 4.0, 4.0, 4.0, 1.0),
+                 grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100):
+        self.posnet, self.normnet = posnet, normnet
+        self.dataset = dataset
+        dev = posnet.device
+        self.device = dev
+        self.pos_lr, self.norm_lr = pos_lr, norm_lr
+        self.grad_crip = grad_crip
+        self.betas, self.eps = betas, eps
+        self.bnf_start_epoch = bnf_start_epoch
+        self.loss_engine = LossEngine(n_mesh, dev, bnfloop=bnfloop, k=k)
+        self.peng = posnet._get_engine(dataset)
+        self.neng = normnet._get_engine(dataset)
+        self.m = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+        self.v = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.epoch = 0          # drives the BNF gate (main.py:101)
+        self.t = 0              # optimiser step count (Adam bias correction)
+        self.lossbuf = None
+
+    @torch.no_grad()
+    def step(self):
+        self.epoch += 1
+        self.t += 1
+        pa, na = self.posnet.arena.data, self.normnet.arena.data
+        pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
+        pos = self.peng.forward(pa, update_running=True)
+        norm = self.neng.forward(na, update_running=True)
+        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
+        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
+        self.peng.backward(pa, pg, dpos)
+        self.neng.backward(na, ng, dnorm)
+        if self.peng.comm.world_size > 1:
+            self.posnet._reduce_grads()
+            self.normnet._reduce_grads()
+        ops.grad_sumsq(ng, out=self.sumsq)                                  # clip NormalNet only (main.py:108)
+        ops.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+        ops.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
+                       clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        self.lossbuf = lossbuf
+        self.pos, self.norm = pos, norm
+        return lossbuf[5]

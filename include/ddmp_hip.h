@@ -1,0 +1,199 @@
+/* libddmp_hip -- C ABI of the MI355X (gfx950) dual-GCN mesh-denoising hot path.
+ *
+ * Drop-in boundary: the reference (astaka-pe/Dual-DMP) has no FFI layer;
+ * its hot path calls the Python operator API of torch_geometric / torch at
+ *   util/networks.py:15-26,51-62,76-87,112-123   GCNConv(in,out)(x, edge_index)
+ *   util/networks.py:31-44,64-67,125-129         BatchNorm1d / LeakyReLU / Linear heads
+ *   util/loss.py:16,37,55,86,140,261             the five losses + mad
+ *   main.py:106-110                              backward, clip_grad_norm_, Adam.step
+ * This library is what a ctypes/cffi binding for that path binds instead.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - matrices are row-major float32 with an explicit leading dimension (elements);
+ *   - the library never allocates or frees caller-visible memory: outputs and workspaces are
+ *     caller-owned (PyTorch tensors in the Python host side); only ddmp_graph owns device memory;
+ *   - work is enqueued on the caller's hipStream_t (void* here so the header needs no HIP);
+ *     nothing synchronises the stream except the *_host helpers and ddmp_graph_create;
+ *   - return value: 0 = OK, < 0 = invalid argument (DDMP_E*), > 0 = hipError_t;
+ *     nothing throws across the ABI.
+ */
+#ifndef DDMP_HIP_H
+#define DDMP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDMP_OK 0
+#define DDMP_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported width) */
+#define DDMP_ERANGE (-2)      /* index out of range in an input table */
+#define DDMP_ENOMEM (-3)      /* host allocation failed */
+#define DDMP_EWORKSPACE (-4)  /* caller workspace too small */
+
+#define DDMP_ABI_VERSION 1
+
+typedef struct ddmp_graph ddmp_graph;
+typedef void* ddmp_stream;    /* hipStream_t */
+
+int ddmp_abi_version(void);
+const char* ddmp_status_string(int status);
+
+/* ------------------------------------------------------------------ graph (gcn_norm, once)
+ * Replaces the per-call `gcn_norm` of PyG 2.2.0 GCNConv (cached=False: recomputed 24x per step
+ * in the reference, util/networks.py:51-62).  edge_index is the reference's [2, nnz] int64
+ * tensor (row 0 = source j, row 1 = target i; util/datamaker.py:90-92), no self loops needed:
+ * explicit self loops are dropped and exactly one per node is added (add_remaining_self_loops),
+ * multi-edges keep their multiplicity.  CSR row i lists the sources of i (ascending) plus i.
+ * dinv[i] = (1 + in-degree(i))^-1/2.
+ */
+int ddmp_csr_build_host(int64_t n_nodes, int64_t nnz, const int64_t* edge_index_host,
+                        int32_t* rowptr_host /*[n+1]*/, int32_t* col_host /*[nnz_out]*/,
+                        float* dinv_host /*[n]*/, int64_t* nnz_out /*in: capacity, out: used*/);
+/* breadth-first (Cuthill-McKee style) node order for gather locality: order[k] = old id */
+int ddmp_csr_bfs_order_host(int64_t n_nodes, const int32_t* rowptr_host, const int32_t* col_host,
+                            int32_t* order_host /*[n]*/);
+
+int ddmp_graph_create(int64_t n_nodes, int64_t nnz, const int64_t* edge_index, int edge_index_on_device,
+                      ddmp_graph** out);
+/* from ready CSR tables on the host (partitioned graphs: n_rows owned rows, cols < n_cols) */
+int ddmp_graph_create_csr_host(int64_t n_rows, int64_t n_cols, const int32_t* rowptr_host,
+                               const int32_t* col_host, const float* dinv_host, ddmp_graph** out);
+int ddmp_graph_destroy(ddmp_graph* g);
+int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int* max_row_nnz);
+int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t** col, const float** dinv);
+
+/* ------------------------------------------------------------------ aggregation  Y = A_hat . f(X) (+ bias)
+ * Replaces GCNConv.propagate (index_select * norm -> scatter_add) and the `+ bias`.
+ * A_hat = D^-1/2 (A + I) D^-1/2 is symmetric for the reference's graphs, so the same call is
+ * the backward aggregation.  Optional fused prologue f(x) = LeakyReLU(pro_scale[c]*x + pro_shift[c])
+ * (the BatchNorm1d + LeakyReLU of the previous layer, util/networks.py:51-62) applied to every
+ * gathered element; pass NULL/NULL for f = identity.  C must be > 0; the vector path needs
+ * C % 4 == 0 and ldx, ldy % 4 == 0, other widths take a scalar path.
+ */
+int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                  const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+                  ddmp_stream stream);
+
+/* ------------------------------------------------------------------ dense steps (MFMA, exact f32)
+ * Replace GCNConv.lin (X.W^T, no bias) and its autograd (dX = dH.W, dW = dH^T.X).
+ *   nt : Y[n,M] = f(A[n,K]) . W[M,K]^T (+ bias[M])       forward / dgrad with a transposed table
+ *   nn : Y[n,K] =   A[n,M]  . W[M,K]                     dgrad
+ *   tn : dW[M,K] = G[n,M]^T . f(Z[n,K])                  wgrad, split over rows; needs workspace
+ * f as in ddmp_spmm_f32 (per column of A resp. Z).  K, lda, ldz must be multiples of 4.
+ */
+int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
+                     int64_t n_rows, int K, int M, const float* bias,
+                     const float* pro_scale, const float* pro_shift, float slope, ddmp_stream stream);
+int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
+                     int64_t n_rows, int M, int K, ddmp_stream stream);
+size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
+int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW, int64_t lddw,
+                     int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift,
+                     float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d (train mode) + LeakyReLU
+ * Replace nn.BatchNorm1d(C) in train mode + nn.LeakyReLU() (util/networks.py:31-44,51-62): batch
+ * statistics over all n rows, biased variance, running stats with `momentum`.  Statistics are
+ * float64 column sums (sum, sumsq) so that several devices can add theirs before `prepare`.
+ * The normalise+activate is expressed as z = LeakyReLU(scale[c]*y + shift[c]) and is applied by the
+ * CONSUMER kernels (pro_scale / pro_shift arguments); ddmp_bn_lrelu_apply_f32 materialises it.
+ * Widths: C a power of two in [8, 1024].  Workspace: ddmp_colreduce_workspace_bytes(n_rows, C).
+ */
+size_t ddmp_colreduce_workspace_bytes(int64_t n_rows, int C);
+int ddmp_bn_stats_f32(const float* Y, int64_t ldy, int64_t n_rows, int C, double* sums /*[2C]*/,
+                      void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_prepare_f32(const double* sums /*[2C]*/, double n_total, int C, const float* gamma,
+                        const float* beta, float eps, float momentum, float* scale, float* shift,
+                        float* mean, float* rstd, float* running_mean /*nullable*/,
+                        float* running_var /*nullable*/, ddmp_stream stream);
+int ddmp_bn_lrelu_apply_f32(const float* Y, int64_t ldy, float* Z, int64_t ldz, int64_t n_rows, int C,
+                            const float* scale, const float* shift, float slope, ddmp_stream stream);
+/* backward: sums2 = (sum g, sum g*yhat), g = dZ * LeakyReLU'(scale*y+shift), yhat = (y-mean)*rstd */
+int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t n_rows, int C,
+                           const float* scale, const float* shift, const float* mean, const float* rstd,
+                           float slope, double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes,
+                           ddmp_stream stream);
+/* sums2 -> dgamma, dbeta and the two folded constants of dY = scale*g + c1*y + c0 */
+int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const float* scale, const float* mean,
+                            const float* rstd, float* dgamma, float* dbeta, float* c1, float* c0,
+                            ddmp_stream stream);
+/* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias) */
+int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, float* dY, int64_t lddy,
+                          int64_t n_rows, int C, const float* scale, const float* shift, const float* c1,
+                          const float* c0, float slope, double* dbias_sums /*[C]*/, void* workspace,
+                          size_t workspace_bytes, ddmp_stream stream);
+int ddmp_colsum_f32(const float* X, int64_t ldx, int64_t n_rows, int C, double* sums /*[C]*/, void* workspace,
+                    size_t workspace_bytes, ddmp_stream stream);
+int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_stream stream);
+
+/* ------------------------------------------------------------------ output heads
+ * Replace linear1 -> LeakyReLU -> linear2 (+ residual | tanh + row normalise), util/networks.py:64-67
+ * (kind 0, PosNet: out = x_pos + u) and :125-129 (kind 1, NormalNet: out = tanh(u)/(|tanh(u)|+1e-12)).
+ * Y is the conv12 output [n,32]; its BatchNorm+LeakyReLU is the scale/shift prologue.  W1 [16,32],
+ * b1 [16], W2 [3,16], b2 [3]; out / dout [n,3] contiguous.  Backward writes dZ [n,32] (gradient w.r.t.
+ * the activated conv12 features) and overwrites the four parameter gradients.
+ */
+int ddmp_head_fwd_f32(const float* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                      float slope, const float* W1, const float* b1, const float* W2, const float* b2,
+                      int kind, const float* x_pos /*kind 0*/, float* out, ddmp_stream stream);
+size_t ddmp_head_bwd_workspace_bytes(int64_t n_rows);
+int ddmp_head_bwd_f32(const float* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                      float slope, const float* W1, const float* b1, const float* W2, const float* b2,
+                      int kind, const float* dout, float* dZ, int64_t lddz, float* dW1, float* db1,
+                      float* dW2, float* db2, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+
+/* ------------------------------------------------------------------ losses (util/loss.py)
+ * Index tables are int32 device arrays: faces [F,3], f2f [F,3] (-1 padded, symmetric on valid entries),
+ * vv_ptr/vv_idx = 1-ring CSR without self (util/mesh.py:189-197), vf_ptr/vf_corner = vertex -> incident
+ * (3*face + corner).  Targets are float64 as in the reference (n_mesh.vs / n_mesh.fn are f64 numpy).
+ * `partials` (ddmp_loss_partials_bytes()) collects per-block float64 sums of S1..S5 and sigma_c;
+ * ddmp_loss_finalize turns them into
+ *   lossbuf[0..4] = pos_rec (:16), laplacian (:37), norm_rec (:55), fn_bnf (:86, ungated), pos_norm (:140)
+ *   lossbuf[5]    = k1*L1 + k2*L2 + k3*L3 + k4*gate4*L4 + k5*L5        (main.py:101-106)
+ *   lossbuf[6..10]= gradient coefficients c1..c5 consumed by the *_bwd calls, lossbuf[11] = sigma_c.
+ * The *_bwd calls take `coef` = device double[5] (c1..c5); a zero coefficient switches a term off.
+ */
+size_t ddmp_loss_partials_bytes(void);
+int ddmp_loss_vertex_fwd(int64_t V, const float* pos, const double* real_pos, const int32_t* vv_ptr,
+                         const int32_t* vv_idx, float* resid /*[V,3]*/, double* partials, ddmp_stream stream);
+int ddmp_loss_face_fwd(int64_t F, const float* pos, const float* norm, const double* real_norm,
+                       const int32_t* faces, float* fc /*[F,3]*/, float* fa /*[F]*/, float* pn_coef /*[F,3]*/,
+                       float* pn_dn /*[F,3]*/, double* partials, ddmp_stream stream);
+int ddmp_loss_bnf_fwd(int64_t F, const float* norm, const int32_t* f2f, const float* fc, const float* fa,
+                      int loop, float* fcd /*[F,3]*/, float* bnf_n /*[loop+1,F,3]*/, float* bnf_A /*[loop,F,3]*/,
+                      double* partials, ddmp_stream stream);
+int ddmp_loss_finalize(const double* partials, int64_t V, int64_t F, const double* k_host /*[5]*/, double gate4,
+                       double* lossbuf /*[12]*/, ddmp_stream stream);
+int ddmp_loss_bnf_bwd(int64_t F, const int32_t* f2f, const float* fa, const float* fcd, int loop,
+                      const float* bnf_n, const float* bnf_A, const double* partials, const double* coef,
+                      float* G0 /*[F,3]*/, float* scratch /*[2,F,3]*/, ddmp_stream stream);
+int ddmp_loss_face_bwd(int64_t F, const float* norm, const double* real_norm, const float* pn_dn,
+                       const float* G0 /*nullable*/, const float* n_last /*with G0*/, const double* coef,
+                       float* dnorm /*[F,3]*/, ddmp_stream stream);
+int ddmp_loss_vertex_bwd(int64_t V, const float* pos, const double* real_pos, const float* resid,
+                         const int32_t* vv_ptr, const int32_t* vv_idx, const int32_t* vf_ptr,
+                         const int32_t* vf_corner, const float* pn_coef, const float* norm, const double* coef,
+                         float* dpos /*[V,3]*/, ddmp_stream stream);
+
+/* ------------------------------------------------------------------ clip_grad_norm_ + Adam (main.py:108-110)
+ * One flat float32 arena per net for param / grad / exp_avg / exp_avg_sq.  clip: coefficient
+ * min(1, max_norm / (sqrt(sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_); Adam: torch defaults
+ * (no weight decay, no amsgrad), `step` is 1-based.  Passing clip_sumsq to ddmp_adam_step_f32 applies
+ * the clip on the fly (grad buffer left unscaled); ddmp_grad_clip_f32 scales it in place instead.
+ */
+size_t ddmp_sumsq_workspace_bytes(void);
+int ddmp_grad_sumsq_f32(const float* g, int64_t n, double* out /*[1]*/, void* workspace, size_t workspace_bytes,
+                        ddmp_stream stream);
+int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm, ddmp_stream stream);
+int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
+                       ddmp_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDMP_HIP_H */

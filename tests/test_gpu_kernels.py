@@ -1,0 +1,228 @@
+"""Parity of every HIP kernel (called through the C ABI) against float64 PyTorch-CPU restatements.
+
+Tolerances (stated per test): the kernels compute in exact f32 (f32 FMA / f32-input MFMA), statistics in
+f64; against a float64 reference the expected error is f32 round-off: rel-L2 <= 1e-5 per op.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def graphs(dev):
+    from dual_dmp_amd import synth, ops
+    from dual_dmp_amd.mesh import Mesh
+    out = {}
+    for name, (v, f) in {"ico3": synth.icosphere(3), "grid": synth.open_grid(9, 7)}.items():
+        v, f = synth.permute_vertices(v, f, 1)
+        m = Mesh(vs=v, faces=f)
+        e = torch.tensor(m.edges.T, dtype=torch.long)
+        ei = torch.cat([e, e[[1, 0]]], 1)
+        fi = torch.from_numpy(m.f_edges)
+        out[name + "_v"] = (ei, len(v))
+        out[name + "_f"] = (fi, len(f))
+    return out
+
+
+def dense_ahat(ei, n):
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
+    A += torch.eye(n, dtype=torch.float64)
+    d = A.sum(1).pow(-0.5)
+    return d[:, None] * A * d[None, :]
+
+
+def f_ref(x, a, b, slope=0.01):
+    z = x * a + b
+    return torch.where(z > 0, z, slope * z)
+
+
+def test_graph_tables_match_gcn_norm(dev, graphs, oracle):
+    from dual_dmp_amd import ops
+    ei, n = graphs["grid_v"]
+    rowptr, col, dinv = ops.csr_build_host(ei.numpy(), n)
+    row, colo, w = oracle.gcn_norm(ei, n, torch.float64)
+    deg = torch.zeros(n, dtype=torch.float64).scatter_add_(0, colo, torch.ones_like(w))
+    np.testing.assert_allclose(dinv, deg.pow(-0.5).numpy(), rtol=1e-7)
+    assert rowptr[-1] == ei.shape[1] + n
+    g = ops.graph_for(ei.to(dev), n)
+    assert (g.n_rows, g.n_cols, g.nnz) == (n, n, ei.shape[1] + n)
+
+
+@pytest.mark.parametrize("C", [8, 16, 32, 64, 128, 256, 512, 3, 20])
+@pytest.mark.parametrize("gname", ["ico3_v", "grid_f"])
+def test_spmm_matches_dense(dev, graphs, C, gname):
+    from dual_dmp_amd import ops
+    ei, n = graphs[gname]
+    torch.manual_seed(C)
+    x = torch.randn(n, C)
+    bias = torch.randn(C)
+    a, b = torch.rand(C) + 0.5, torch.randn(C)
+    A = dense_ahat(ei, n)
+    g = ops.graph_for(ei.to(dev), n)
+    y = ops.spmm(g, x.to(dev))
+    assert relerr(y, A @ x.double()) < 1e-6
+    y = ops.spmm(g, x.to(dev), bias=bias.to(dev), pro=(a.to(dev), b.to(dev)))
+    ref = A @ f_ref(x.double(), a.double(), b.double()) + bias.double()
+    assert relerr(y, ref) < 1e-6
+
+
+def test_spmm_multi_edges_and_self_loops(dev):
+    from dual_dmp_amd import ops
+    ei = torch.tensor([[0, 1, 1, 2, 2, 0, 1, 3, 3], [1, 0, 2, 1, 0, 2, 0, 3, 3]])
+    n = 5                                               # node 4 isolated, node 3 only explicit self loops
+    x = torch.randn(n, 32)
+    y = ops.spmm(ops.graph_for(ei.to(dev), n), x.to(dev))
+    keep = ei[:, ei[0] != ei[1]]
+    assert relerr(y, dense_ahat(keep, n) @ x.double()) < 1e-6
+
+
+@pytest.mark.parametrize("n,K,M", [(1000, 32, 64), (777, 512, 512), (130, 8, 32), (513, 256, 128),
+                                   (300, 16, 32), (2000, 64, 32), (129, 128, 256), (50, 32, 3)])
+def test_gemm_nt_nn_tn(dev, n, K, M):
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    a, w, bias = torch.randn(n, K), torch.randn(M, K) / K ** 0.5, torch.randn(M)
+    sc, sh = torch.rand(K) + 0.5, torch.randn(K)
+    y = ops.gemm_nt(a.to(dev), w.to(dev), bias=bias.to(dev))
+    assert relerr(y, a.double() @ w.double().t() + bias.double()) < 2e-6
+    y = ops.gemm_nt(a.to(dev), w.to(dev), pro=(sc.to(dev), sh.to(dev)))
+    assert relerr(y, f_ref(a.double(), sc.double(), sh.double()) @ w.double().t()) < 2e-6
+    if M % 4 == 0:
+        g = torch.randn(n, M)
+        dx = ops.gemm_nn(g.to(dev), w.to(dev))
+        assert relerr(dx, g.double() @ w.double()) < 2e-6
+        dw = ops.gemm_tn(g.to(dev), a.to(dev))
+        assert relerr(dw, g.double().t() @ a.double()) < 2e-6
+        dw = ops.gemm_tn(g.to(dev), a.to(dev), pro=(sc.to(dev), sh.to(dev)))
+        assert relerr(dw, g.double().t() @ f_ref(a.double(), sc.double(), sh.double())) < 2e-6
+
+
+def test_gemm_transpose_detecting(dev):
+    """A = I with an asymmetric W: a swapped C-write would show."""
+    from dual_dmp_amd import ops
+    n = 128
+    a = torch.eye(n)
+    w = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / n
+    y = ops.gemm_nt(a.to(dev), w.to(dev))
+    assert torch.equal(y.cpu(), w.t())
+    assert torch.equal(ops.gemm_nn(a.to(dev), w.to(dev)).cpu(), w)
+    assert torch.equal(ops.gemm_tn(a.to(dev), w.to(dev)).cpu(), w)
+
+
+@pytest.mark.parametrize("n,C", [(642, 32), (1280, 512), (100, 8), (3000, 256)])
+def test_batchnorm_lrelu_forward_backward(dev, n, C):
+    from dual_dmp_amd import ops
+    torch.manual_seed(C)
+    y = (torch.randn(n, C) * 2 + 3).requires_grad_(True)
+    gamma, beta = (torch.rand(C) + 0.5).requires_grad_(True), torch.randn(C).requires_grad_(True)
+    dz = torch.randn(n, C)
+    bn = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    yd = y.detach().double().requires_grad_(True)
+    z = torch.nn.functional.leaky_relu(bn(yd), 0.01)
+    z.backward(dz.double())
+
+    yg = y.detach().to(dev)
+    sums = ops.bn_stats(yg)
+    bn4 = torch.empty(4, C, device=dev)
+    run = torch.stack([torch.zeros(C), torch.ones(C)]).to(dev)
+    ops.bn_prepare(sums, n, gamma.detach().to(dev), beta.detach().to(dev), bn4, running=(run[0], run[1]))
+    zz = ops.bn_lrelu_apply(yg, bn4[0], bn4[1])
+    assert relerr(zz, z) < 2e-6
+    assert relerr(run[0], bn.running_mean) < 1e-6 and relerr(run[1], bn.running_var) < 1e-6
+    sums2 = ops.bn_bwd_reduce(dz.to(dev), yg, bn4)
+    dgamma, dbeta, c10 = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(2, C, device=dev)
+    ops.bn_bwd_prepare(sums2, n, bn4, dgamma, dbeta, c10)
+    dy = torch.empty(n, C, device=dev)
+    dbs = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    ops.bn_bwd_apply(dz.to(dev), yg, bn4, c10, dy, dbs)
+    assert relerr(dy, yd.grad) < 1e-5
+    assert relerr(dgamma, bn.weight.grad) < 1e-5 and relerr(dbeta, bn.bias.grad) < 1e-5
+    # conv-bias gradient = column sums of dY: analytically zero after BN
+    assert float(dbs[:C].abs().max()) < 1e-3 * float(yd.grad.abs().sum(0).max())
+    assert relerr(ops.colsum(dz.to(dev)), dz.double().sum(0)) < 1e-7
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_heads_forward_backward(dev, kind):
+    from dual_dmp_amd import ops
+    torch.manual_seed(kind)
+    n = 1500
+    y = torch.randn(n, 32)
+    a, b = torch.rand(32) + 0.5, torch.randn(32)
+    W1, b1 = (torch.randn(16, 32) / 5).requires_grad_(True), torch.randn(16).requires_grad_(True)
+    W2, b2 = (torch.randn(3, 16) / 3).requires_grad_(True), torch.randn(3).requires_grad_(True)
+    x_pos = torch.randn(n, 3)
+    dout = torch.randn(n, 3)
+    z = f_ref(y.double(), a.double(), b.double()).requires_grad_(True)
+    t = torch.nn.functional.leaky_relu(z @ W1.double().t() + b1.double(), 0.01)
+    u = t @ W2.double().t() + b2.double()
+    if kind == 0:
+        out = x_pos.double() + u
+    else:
+        v = torch.tanh(u)
+        out = v * torch.reciprocal(torch.norm(v, dim=1, keepdim=True) + 1e-12)
+    gz, gW1, gb1, gW2, gb2 = torch.autograd.grad(out, [z, W1, b1, W2, b2], dout.double())
+
+    bn4 = torch.stack([a, b, torch.zeros(32), torch.ones(32)]).to(dev)
+    P = [p.detach().to(dev).contiguous() for p in (W1, b1, W2, b2)]
+    o = torch.empty(n, 3, device=dev)
+    ops.head_fwd(y.to(dev), bn4, *P, kind, x_pos.to(dev), o)
+    assert relerr(o, out) < 2e-6
+    dz = torch.empty(n, 32, device=dev)
+    G = [torch.empty_like(p) for p in P]
+    ops.head_bwd(y.to(dev), bn4, *P, kind, dout.to(dev), dz, *G)
+    assert relerr(dz, gz) < 1e-5
+    for got, ref in zip(G, (gW1, gb1, gW2, gb2)):
+        assert relerr(got, ref) < 1e-5
+
+
+def test_clip_and_adam_match_torch(dev):
+    from dual_dmp_amd import ops
+    torch.manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=0.01)
+    p = p0.to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        g = torch.randn(n) * (3.0 if step % 2 else 1e-3)
+        pt.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 0.8)
+        opt.step()
+        gd = g.to(dev)
+        ss = ops.grad_sumsq(gd)
+        ops.adam_step_(p, gd, m, v, 0.01, step, clip_sumsq=ss, max_norm=0.8)
+        assert relerr(p, pt.detach()) < 1e-6
+        g2 = gd.clone()
+        ops.grad_clip_(g2, ss, 0.8)
+        assert relerr(g2, pt.grad) < 1e-6
+    # without clip
+    ops.adam_step_(p, gd, m, v, 0.01, 6)
+    pt.grad = g.clone()
+    opt.step()
+    assert relerr(p, pt.detach()) < 1e-6
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing elsewhere."""
+    from dual_dmp_amd import ops, _lib
+    with pytest.raises(_lib.DdmpError):
+        ops.gemm_nt(torch.randn(8, 8), torch.randn(8, 8))
