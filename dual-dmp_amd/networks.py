@@ -93,7 +93,7 @@ class _FusedNet(nn.Module):
                     v.copy_(sd[name].to(v.device, torch.float32))
                 elif strict:
                     raise KeyError("missing key %s" % name)
-        self._pending_running = {k: v for k, v in sd.items() if "running_" in k}
+        self._pending_running = {k: v.detach().clone() for k, v in sd.items() if "running_" in k}
         return self
 
     # ------------------------------------------------------------ engine plumbing

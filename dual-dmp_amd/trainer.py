@@ -61,3 +61,16 @@ class FusedTrainer:
         self.lossbuf = lossbuf
         self.pos, self.norm = pos, norm
         return lossbuf[5]
+
+    # ------------------------------------------------------------------ state injection (parity harness)
+    def load_adam_state(self, which: int, exp_avg: dict, exp_avg_sq: dict, t: int):
+        """Set the Adam moments of net `which` (0 = PosNet, 1 = NormalNet) from reference-named tensors
+        (as found in ``torch.optim.Adam.state``) and the shared step count."""
+        net = (self.posnet, self.normnet)[which]
+        self.m[which].zero_()
+        self.v[which].zero_()
+        for name, *_ in net.layout.entries:
+            if name in exp_avg:
+                net.layout.view(self.m[which], name).copy_(exp_avg[name].to(self.device))
+                net.layout.view(self.v[which], name).copy_(exp_avg_sq[name].to(self.device))
+        self.t = int(t)
