@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training iterations/sec (+ MAD) of the Dual-DMP step on a synthetic 1M-face mesh.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = main.py:88-110 of the reference (two GCN forwards, five losses, backward, clip on NormalNet,
+two Adam updates) + the loss.item() sync (main.py:113).  Inputs are resident in HBM before the timed region.
+Workload = BASELINE.json configs[2]: synthetic manifold mesh, 1,000,000 faces / 500,000 vertices (torus grid),
+unit mean edge, Gaussian noise 0.2 along vertex normals (seed 314), 30-step Laplacian smooth, z1 seed 314,
+weights seed 0, k=(3,4,4,4,1), bnfloop=1, lr 0.01, float32.  N > 1: the same mesh is face/vertex-partitioned
+over N ranks with 1-hop halos (strong scaling), see dual-dmp_amd/dist.py.
+
+Rank 0 prints ONE JSON line (schema in the task contract) with two extra objects:
+  roofline      dominant kernel family of the step (by summed time), measured with HIP events on the launch
+                stream in a separate profiled pass of the same step; + "roofline_gather" for the GCN gather
+  cpu_baseline  the oracle's PyG-shaped PyTorch-CPU training step timed on this host (bounded sample)
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def load_oracle():
+    spec = importlib.util.spec_from_file_location("ddmp_oracle", os.path.join(ROOT, "oracle", "ddmp_oracle.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault("ddmp_oracle", mod)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def torus_dims(faces):
+    """nu x nv with 2*nu*nv == faces and nu = 2*nv (1,000,000 -> 1000 x 500)."""
+    nv = int(round((faces / 4.0) ** 0.5))
+    nu = faces // (2 * nv)
+    return nu, nv
+
+
+def build_case(faces, order):
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    nu, nv = torus_dims(faces)
+    v, f = synth.torus(nu, nv)
+    if order == "random":
+        v, f = synth.permute_vertices(v, f, 0)
+        f = synth.permute_faces(f, 0)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
+
+
+def _oracle_setup(oracle, faces):
+    gt, noisy, smooth, _ = build_case(faces, "native")
+    odata = oracle.OracleDataset(noisy, smooth)
+    torch.manual_seed(0)
+    pn, nn_ = oracle.PosNetRef(), oracle.NormalNetRef()
+    args = oracle.StepArgs()
+    op = torch.optim.Adam(pn.parameters(), lr=args.pos_lr)
+    on = torch.optim.Adam(nn_.parameters(), lr=args.norm_lr)
+    return lambda ep: oracle.train_step(pn, nn_, op, on, odata, noisy, args, ep), noisy
+
+
+def cpu_baseline(sample_faces, target_faces, iters=2):
+    """Oracle (PyG-shaped PyTorch CPU restatement) timed on this host, bounded to ~10-30 s: the thread count is
+    calibrated first (PyTorch's default = all cores thrashes on many-core hosts: 256 threads measured 40x slower
+    than 8 on this workload), then 1 warm-up + `iters` timed iterations of the same step on a smaller torus of
+    the same family; reported linearly extrapolated to the bench size (the step is O(faces))."""
+    oracle = load_oracle()
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
+    step, _ = _oracle_setup(oracle, 5000)
+    best, best_dt = cands[0], float("inf")
+    for t in cands:
+        torch.set_num_threads(t)
+        step(1)
+        t0 = time.perf_counter()
+        step(2)
+        dt = time.perf_counter() - t0
+        if dt < best_dt:
+            best, best_dt = t, dt
+    torch.set_num_threads(best)
+    step, noisy = _oracle_setup(oracle, sample_faces)
+    step(1)
+    t0 = time.perf_counter()
+    for ep in range(2, 2 + iters):
+        step(ep)
+    dt = (time.perf_counter() - t0) / iters
+    F = len(noisy.faces)
+    return {
+        "value": (1.0 / dt) * F / target_faces, "unit": "iters/s", "cores": best, "kind": "port",
+        "sample": "oracle train_step (PyTorch CPU, PyG-shaped index_select*w+index_add per layer), %d faces / %d verts, "
+                  "%d threads (fastest of %s on a %d-core host), 1 warm-up + %d timed iters: %.3f s/iter = %.4f iters/s "
+                  "at that size; value = linear extrapolation to %d faces"
+                  % (F, len(noisy.vs), best, cands, ncpu, iters, dt, 1.0 / dt, target_faces),
+    }
+
+
+def family_table(summary, steps):
+    fam = {}
+    for (name, key), a in summary.items():
+        f = fam.setdefault(name, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+        for k in ("calls", "ms", "bytes", "flops"):
+            f[k] += a[k] / steps
+    return fam
+
+
+def roofline_obj(name, f):
+    ms = f["ms"]
+    if name.startswith("gemm"):
+        ach = f["flops"] / (ms * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                "ms_per_step": round(ms, 3), "launches_per_step": f["calls"]}
+    ach = f["bytes"] / (ms * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "ms_per_step": round(ms, 3), "launches_per_step": f["calls"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--faces", type=int, default=1000000)
+    ap.add_argument("--order", choices=["native", "random"], default="native",
+                    help="vertex/face numbering of the synthetic mesh as handed to the engine")
+    ap.add_argument("--bnfloop", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-faces", type=int, default=20000)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table (JSON) here")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dual_dmp_amd import ops
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    t_setup = time.perf_counter()
+    gt, noisy, smooth, data = build_case(args.faces, args.order)
+    V, F = len(noisy.vs), len(noisy.faces)
+    torch.manual_seed(0)
+    if world > 1:
+        from dual_dmp_amd.dist import make_distributed_trainer
+        tr = make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop)
+        barrier = tr.barrier
+    else:
+        posnet, normnet = PosNet(dev), NormalNet(dev)
+        data.to(dev)
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop)
+        barrier = lambda: None   # noqa: E731
+    setup_s = time.perf_counter() - t_setup
+
+    for _ in range(args.warmup):
+        tr.step().item()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step().item()          # the reference's per-step sync (main.py:113)
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- MAD (outside the timed region): float32 positions -> face normals -> mean angular difference
+    out = {}
+    if rank == 0:
+        from dual_dmp_amd.loss import mad
+        from dual_dmp_amd.mesh import Mesh
+        pos = tr.gather_pos().cpu().numpy() if world > 1 else tr.pos.cpu().numpy()
+        o = Mesh.__new__(Mesh)
+        o.vs, o.faces = pos.astype(np.float64), noisy.faces
+        Mesh.compute_face_normals(o)
+        out["mad_deg"] = {"noisy_input": round(float(mad(noisy.fn, gt.fn)), 4),
+                          "after_%d_iters" % (args.warmup + args.steps): round(float(mad(o.fn, gt.fn)), 4)}
+    elif world > 1:
+        tr.gather_pos()
+
+    # ---- profiled pass (separate from the timed region): HIP events around every launch
+    roof = roof_gather = None
+    table = {}
+    if args.profile_steps > 0:
+        ops.PROF = ops.Profiler()
+        for _ in range(args.profile_steps):
+            tr.step().item()
+        summ = ops.PROF.summary()
+        ops.PROF = None
+        fam = family_table(summ, args.profile_steps)
+        if rank == 0:
+            dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+            roof = roofline_obj(*dom)
+            if "spmm" in fam:
+                roof_gather = roofline_obj("spmm", fam["spmm"])
+            for (name, key), a in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                ms = a["ms"] / args.profile_steps
+                table["%s%s" % (name, list(key) if isinstance(key, tuple) else [key])] = {
+                    "launches_per_step": a["calls"] / args.profile_steps, "ms_per_step": round(ms, 4),
+                    "avg_us_per_launch": round(1e3 * a["ms"] / a["calls"], 2),
+                    "alg_GBs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0,
+                    "TFLOPs": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["ms"] > 0 else 0}
+            out["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_sample_faces, F)
+
+    if rank == 0:
+        line = {
+            "metric": "training iters/sec + MAD score, 1M-face mesh @ 1/2/4/8 MI355X",
+            "value": round(args.steps / elapsed, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, float32, k=(3,4,4,4,1), "
+                                   "bnfloop=%d, %s numbering (BASELINE.json configs[2])" % (F, V, args.bnfloop, args.order),
+                       "faces": F, "verts": V, "parallelism": "1 GPU" if world == 1 else "%d-way face/vertex partition + 1-hop halo" % world,
+                       "setup_s": round(setup_s, 1)},
+            "loss": round(float(loss), 6),
+            "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
+        }
+        line.update(out)
+        if args.kernel_table:
+            os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
+            with open(args.kernel_table, "w") as fh:
+                json.dump({"config": line["config"], "ms_per_step": line["ms_per_step"], "kernels": table}, fh, indent=1)
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

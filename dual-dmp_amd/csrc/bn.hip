@@ -120,17 +120,32 @@ struct ColsumF {
     }
 };
 
-// partial[nblk][width] -> out[width] (double); 64 columns x 4 slices per workgroup
+// partial[nblk][width] -> out[width] (double).  32 columns x 8 row-slices per workgroup; every slice keeps
+// 8 independent loads in flight (the serial form of this loop was latency-bound: 73 us per call).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nblk,
                                                               int width, double* __restrict__ out) {
     __shared__ double sm[256];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
     double t = 0.0;
-    if (c < width)
-        for (int b = sl; b < nblk; b += 4) t += partial[(int64_t)b * width + c];
+    if (c < width) {
+        int b = sl;
+        for (; b + 56 < nblk; b += 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * width + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; b < nblk; b += 8) t += partial[(int64_t)b * width + c];
+    }
     sm[threadIdx.x] = t;
     __syncthreads();
-    if (sl == 0 && c < width) out[c] = sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192];
+    if (sl == 0 && c < width) {
+        double r = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += sm[threadIdx.x + 32 * u];
+        out[c] = r;
+    }
 }
 
 __global__ void bn_prepare_kernel(const double* __restrict__ sums, double n_total, int C,
@@ -202,7 +217,7 @@ int run_colreduce(const F& f, int64_t n_rows, int C, int width, double* out, voi
     hipLaunchKernelGGL((colreduce_kernel<F>), dim3(nblk), dim3(256), 0, st, f, (int)n_rows, C, partial);
     LAUNCH_TRY();
     // partial rows are [2*C]; reduce the first `width` columns (width = C or 2C)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(2 * C, 64)), dim3(256), 0, st, partial, nblk,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, st, partial, nblk,
                        2 * C, out);
     LAUNCH_TRY();
     (void)width;

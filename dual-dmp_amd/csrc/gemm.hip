@@ -288,15 +288,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     }
 }
 
+// dW = sum over splits of the partial tiles; 4 splits x 4 elements in flight per thread
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int64_t split_stride,
                                                             int n_splits, float* __restrict__ dW, int64_t lddw,
                                                             int M, int K) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * K) return;
-    const int m = idx / K, k = idx % K;
-    double s = 0.0;
-    for (int i = 0; i < n_splits; ++i) s += (double)part[(int64_t)i * split_stride + idx];
-    dW[(int64_t)m * lddw + k] = (float)s;
+    const int q = blockIdx.x * 256 + threadIdx.x;      // float4 index (M*K is a multiple of 4)
+    if (q * 4 >= M * K) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = 0;
+    for (; i + 3 < n_splits; i += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(i + u) * split_stride + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+    }
+    for (; i < n_splits; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)i * split_stride + 4 * q);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    const int idx = 4 * q, m = idx / K, k = idx % K;    // K % 4 == 0: the four elements share a row
+    float* o = dW + (int64_t)m * lddw + k;
+    o[0] = (float)s0; o[1] = (float)s1; o[2] = (float)s2; o[3] = (float)s3;
 }
 
 struct TnPlan {
@@ -408,7 +421,7 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     }
 #undef DDMP_LAUNCH_TN
     LAUNCH_TRY();
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, st, part,
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part,
                        sstride, p.n_splits, dW, lddw, M, K);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -168,13 +168,22 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     else if (tid >= 128 && tid < 128 + H2) p[H1 * H0 + H1 + H2 * H1 + (tid - 128)] = accC;
 }
 
-__global__ void head_reduce_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dW1,
-                                   float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kNPar) return;
+// 32 parameters x 8 block-slices per workgroup
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ partial, int nblk,
+                                                          float* __restrict__ dW1, float* __restrict__ db1,
+                                                          float* __restrict__ dW2, float* __restrict__ db2) {
+    __shared__ double sm[256];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * kNPar + i];
-    const float v = (float)s;
+    if (i < kNPar)
+        for (int b = sl; b < nblk; b += 8) s += (double)partial[(int64_t)b * kNPar + i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (sl != 0 || i >= kNPar) return;
+    double r = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r += sm[threadIdx.x + 32 * u];
+    const float v = (float)r;
     if (i < H1 * H0) dW1[i] = v;
     else if (i < H1 * H0 + H1) db1[i - H1 * H0] = v;
     else if (i < H1 * H0 + H1 + H2 * H1) dW2[i - H1 * H0 - H1] = v;
@@ -218,7 +227,7 @@ extern "C" int ddmp_head_bwd_f32(const float* Y, int64_t ldy, int64_t n_rows, co
     hipLaunchKernelGGL(head_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
                        shift, slope, w, kind, dout, dZ, lddz, (float*)ws);
     LAUNCH_TRY();
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)cdiv(kNPar, 128)), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)cdiv(kNPar, 32)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, nblk, dW1, db1, dW2, db2);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -24,6 +24,48 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class Profiler:
+    """Per-call timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream), plus the ALGORITHMIC bytes / flops of each call.
+    Off by default: ``ops.PROF = ops.Profiler()`` switches it on."""
+
+    def __init__(self):
+        self.records = []          # (name, key, alg_bytes, flops, ev0, ev1)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, key, b, f, e0, e1 in self.records:
+            a = agg.setdefault((name, key), dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+            a["calls"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["bytes"] += b
+            a["flops"] += f
+        return agg
+
+
+PROF = None
+
+
+class _timed:
+    __slots__ = ("args", "e0")
+
+    def __init__(self, name, key, alg_bytes=0.0, flops=0.0):
+        self.args = (name, key, alg_bytes, flops)
+
+    def __enter__(self):
+        if PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROF.records.append(self.args + (self.e0, e1))
+        return False
+
+
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -146,7 +188,11 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
         out = torch.empty((g.n_rows, C), dtype=torch.float32, device=x.device)
     out, ldy = _mat(out, "out")
     ps, psh = (None, None) if pro is None else pro
-    st = _lib.lib().ddmp_spmm_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope, _stream())
+    # algorithmic bytes: every feature row read once + written once, int32 col ids, rowptr, dinv
+    alg = 2.0 * g.n_rows * C * 4 + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
+    with _timed("spmm", C, alg, 2.0 * g.nnz * C):
+        st = _lib.lib().ddmp_spmm_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope,
+                                      _stream())
     check(st, "ddmp_spmm_f32")
     return out
 
@@ -163,8 +209,9 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
         out = torch.empty((n, M), dtype=torch.float32, device=a.device)
     out, ldy = _mat(out, "out")
     ps, psh = (None, None) if pro is None else pro
-    st = _lib.lib().ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
-                                     _stream())
+    with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = _lib.lib().ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh),
+                                         slope, _stream())
     check(st, "ddmp_gemm_nt_f32")
     return out
 
@@ -180,7 +227,8 @@ def gemm_nn(a, w, out=None, n_rows=None):
     if out is None:
         out = torch.empty((n, K), dtype=torch.float32, device=a.device)
     out, ldy = _mat(out, "out")
-    st = _lib.lib().ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _stream())
+    with _timed("gemm_nn", (M, K), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = _lib.lib().ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _stream())
     check(st, "ddmp_gemm_nn_f32")
     return out
 
@@ -198,8 +246,9 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
     need = L.ddmp_gemm_tn_workspace_bytes(n, M, K)
     ws = Workspace.get(need, g.device)
     ps, psh = (None, None) if pro is None else pro
-    st = L.ddmp_gemm_tn_f32(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _p(ps), _p(psh), slope, _p(ws),
-                            ws.numel(), _stream())
+    with _timed("gemm_tn", (M, K), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_tn_f32(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _p(ps), _p(psh), slope, _p(ws),
+                                ws.numel(), _stream())
     check(st, "ddmp_gemm_tn_f32")
     return out
 
@@ -219,7 +268,8 @@ def bn_stats(y, sums=None, n_rows=None):
     if sums is None:
         sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
-    st = _lib.lib().ddmp_bn_stats_f32(_p(y), ldy, n, C, _p(sums), _p(ws), ws.numel(), _stream())
+    with _timed("bn_stats", C, 4.0 * n * C):
+        st = _lib.lib().ddmp_bn_stats_f32(_p(y), ldy, n, C, _p(sums), _p(ws), ws.numel(), _stream())
     check(st, "ddmp_bn_stats_f32")
     return sums
 
@@ -253,8 +303,9 @@ def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None):
     if sums2 is None:
         sums2 = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
-    st = _lib.lib().ddmp_bn_bwd_reduce_f32(_p(dz), lddz, _p(y), ldy, n, C, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
-                                           _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+    with _timed("bn_bwd_reduce", C, 8.0 * n * C):
+        st = _lib.lib().ddmp_bn_bwd_reduce_f32(_p(dz), lddz, _p(y), ldy, n, C, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
+                                               _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
     check(st, "ddmp_bn_bwd_reduce_f32")
     return sums2
 
@@ -274,8 +325,10 @@ def bn_bwd_apply(dz, y, bn4, c10, dy, dbias_sums, slope=SLOPE, n_rows=None):
     n = y.shape[0] if n_rows is None else n_rows
     C = y.shape[1]
     ws = _colws(n, C, y.device)
-    st = _lib.lib().ddmp_bn_bwd_apply_f32(_p(dz), lddz, _p(y), ldy, _p(dy), lddy, n, C, _p(bn4[0]), _p(bn4[1]),
-                                          _p(c10[0]), _p(c10[1]), slope, _p(dbias_sums), _p(ws), ws.numel(), _stream())
+    with _timed("bn_bwd_apply", C, 12.0 * n * C):
+        st = _lib.lib().ddmp_bn_bwd_apply_f32(_p(dz), lddz, _p(y), ldy, _p(dy), lddy, n, C, _p(bn4[0]), _p(bn4[1]),
+                                              _p(c10[0]), _p(c10[1]), slope, _p(dbias_sums), _p(ws), ws.numel(),
+                                              _stream())
     check(st, "ddmp_bn_bwd_apply_f32")
     return dy
 
@@ -301,8 +354,9 @@ def f64_to_f32(src, dst):
 def head_fwd(y, bn4, W1, b1, W2, b2, kind, x_pos, out, slope=SLOPE, n_rows=None):
     y, ldy = _mat(y, "y")
     n = y.shape[0] if n_rows is None else n_rows
-    st = _lib.lib().ddmp_head_fwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2),
-                                      kind, _p(x_pos), _p(out), _stream())
+    with _timed("head_fwd", kind, 4.0 * n * (32 + 3 + (3 if kind == 0 else 0))):
+        st = _lib.lib().ddmp_head_fwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2),
+                                          _p(b2), kind, _p(x_pos), _p(out), _stream())
     check(st, "ddmp_head_fwd_f32")
     return out
 
@@ -313,8 +367,10 @@ def head_bwd(y, bn4, W1, b1, W2, b2, kind, dout, dz, dW1, db1, dW2, db2, slope=S
     n = y.shape[0] if n_rows is None else n_rows
     L = _lib.lib()
     ws = Workspace.get(L.ddmp_head_bwd_workspace_bytes(n), y.device)
-    st = L.ddmp_head_bwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2), kind,
-                             _p(dout), _p(dz), lddz, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(ws), ws.numel(), _stream())
+    with _timed("head_bwd", kind, 4.0 * n * (32 + 3 + 32)):
+        st = L.ddmp_head_bwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2), kind,
+                                 _p(dout), _p(dz), lddz, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(ws), ws.numel(),
+                                 _stream())
     check(st, "ddmp_head_bwd_f32")
 
 
