@@ -1,0 +1,316 @@
+"""Multi-GPU execution of the training step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device; this is the build's own row (e).  What shards and how:
+
+* The two GCN stacks (99 % of the step) are ROW-partitioned: the face graph over P contiguous chunks of a
+  Morton order of the face centroids, the vertex graph by "owner of the vertex's first incident face".
+  Rank r keeps its owned rows plus a 1-hop halo (rows [n_rows, n_cols)) and a local CSR whose columns
+  index [owned | halo]; ``dinv`` comes from the GLOBAL degrees.
+* Per layer and direction the ONLY feature exchange is the tensor about to be gathered (width
+  min(C_in, C_out)): ``all_to_all_single`` of the boundary rows straight into the halo rows.  Because
+  A_hat is symmetric the backward aggregation is the same gather, so no reverse scatter-add exists.
+* BatchNorm statistics: float64 column sums all-reduced (2*C values) before ``bn_prepare`` /
+  ``bn_bwd_prepare``; weight gradients: one all-reduce of the flat gradient arena per net and step
+  (BN weight/bias gradients are already global and are excluded from the sum).
+* The five losses are O(V+F) streaming work (<2 % of the step) full of global quirks (sigma_c over all
+  faces, -1 -> LAST face): they are REPLICATED: ``pos``/``norm`` of the owned rows are all-reduced into full
+  arrays, every rank runs the unchanged :class:`loss.LossEngine` and keeps the gradient rows it owns.
+* Parameters are replicated; identical reduced gradients + identical Adam state keep them bit-identical.
+
+Communicators: :class:`TorchDistComm` (nccl = RCCL on GPUs, gloo in the CPU tests) and :class:`ThreadComm`
+(P logical ranks as threads in ONE process / on ONE device, used to check the partitioned HIP path against
+the unpartitioned one on a single GPU).
+"""
+from __future__ import annotations
+
+import threading
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------ partitioning
+def morton_order(points: np.ndarray) -> np.ndarray:
+    """argsort of 3-D Morton codes (21 bits per axis) of `points` [n,3]."""
+    p = np.asarray(points, dtype=np.float64)
+    lo, hi = p.min(0), p.max(0)
+    q = ((p - lo) / np.maximum(hi - lo, 1e-30) * (2 ** 21 - 1)).astype(np.uint64)
+
+    def spread(x):
+        x &= np.uint64(0x1FFFFF)
+        x = (x | (x << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        x = (x | (x << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        x = (x | (x << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        x = (x | (x << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return x
+
+    code = spread(q[:, 0].copy()) | (spread(q[:, 1].copy()) << np.uint64(1)) | (spread(q[:, 2].copy()) << np.uint64(2))
+    return np.argsort(code, kind="stable")
+
+
+def face_owner_morton(fc: np.ndarray, P: int) -> np.ndarray:
+    """P contiguous chunks of the Morton order of the face centroids, balanced on faces."""
+    order = morton_order(fc)
+    owner = np.empty(len(fc), dtype=np.int32)
+    bounds = np.linspace(0, len(fc), P + 1).astype(np.int64)
+    for r in range(P):
+        owner[order[bounds[r]:bounds[r + 1]]] = r
+    return owner
+
+
+def vertex_owner_from_faces(faces: np.ndarray, face_owner: np.ndarray, n_verts: int) -> np.ndarray:
+    """A vertex belongs to the rank owning its lowest-numbered incident face."""
+    flat = faces.reshape(-1)
+    fid = np.repeat(np.arange(len(faces), dtype=np.int64), 3)
+    first = np.full(n_verts, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first, flat, fid)
+    owner = np.zeros(n_verts, dtype=np.int32)
+    has = first < np.iinfo(np.int64).max
+    owner[has] = face_owner[first[has]]
+    return owner
+
+
+class HaloPlan:
+    """Everything rank `rank` needs for one graph: local CSR over [owned | halo], global ids, and the
+    all-to-all schedule.  Built identically (deterministically) on every rank from the global CSR."""
+
+    def __init__(self, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, owner: np.ndarray, rank: int, P: int):
+        n = len(rowptr) - 1
+        owner = owner.astype(np.int64)
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr).astype(np.int64))
+        colg = col.astype(np.int64)
+        cut = owner[rows] != owner[colg]
+        # (dest rank, needed node) pairs, unique; dest d receives node j from owner[j]
+        key = owner[rows[cut]] * np.int64(n) + colg[cut]
+        key = np.unique(key)
+        dest, node = key // n, key % n
+        src = owner[node]
+        self.rank, self.P = rank, P
+        self.owned = np.flatnonzero(owner == rank).astype(np.int64)            # ascending global ids
+        mine = dest == rank
+        o = np.lexsort((node[mine], src[mine]))                                 # grouped by source rank, then id
+        self.halo = node[mine][o]
+        self.recv_counts = np.bincount(src[mine], minlength=P).astype(np.int64).tolist()
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[self.owned] = np.arange(len(self.owned))
+        g2l[self.halo] = len(self.owned) + np.arange(len(self.halo))
+        out = src == rank
+        o = np.lexsort((node[out], dest[out]))                                  # grouped by dest rank, then id
+        self.send_idx = g2l[node[out][o]]                                       # local owned indices
+        self.send_counts = np.bincount(dest[out], minlength=P).astype(np.int64).tolist()
+        self.n_rows, self.n_cols = len(self.owned), len(self.owned) + len(self.halo)
+        # local CSR over owned rows
+        cnt = np.diff(rowptr).astype(np.int64)[self.owned]
+        self.rowptr = np.zeros(self.n_rows + 1, dtype=np.int32)
+        np.cumsum(cnt, out=self.rowptr[1:])
+        starts = rowptr[self.owned].astype(np.int64)
+        idx = np.repeat(starts - self.rowptr[:-1].astype(np.int64), cnt) + np.arange(int(cnt.sum()), dtype=np.int64)
+        self.col = g2l[colg[idx]].astype(np.int32)
+        assert (self.col >= 0).all()
+        self.local_ids = np.concatenate([self.owned, self.halo])
+        self.dinv = dinv[self.local_ids].astype(np.float32)
+        self.n_global = n
+
+
+# ------------------------------------------------------------------------------------ communicators
+class GraphComm:
+    """Per-graph view of a backend: what :class:`engine.GcnEngine` calls."""
+
+    def __init__(self, backend, plan: HaloPlan, device):
+        self.backend, self.plan = backend, plan
+        self.world_size, self.rank = backend.world_size, backend.rank
+        self.send_idx = torch.from_numpy(plan.send_idx).to(device)
+
+    def halo_exchange(self, t: torch.Tensor, n_rows: int):
+        p = self.plan
+        assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
+        send = t[:n_rows].index_select(0, self.send_idx)
+        recv = t[n_rows:p.n_cols]
+        self.backend.all_to_all(recv, send, p.recv_counts, p.send_counts)
+        return t
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        return self.backend.all_reduce_sum(t)
+
+
+class TorchDistComm:
+    """torch.distributed backend: "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world_size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_to_all(self, recv, send, recv_counts, send_counts):
+        self.dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                    group=self.group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, group=self.group)
+        return t
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class ThreadComm:
+    """P logical ranks = P threads of one process sharing one device.  Collectives are rendezvous through a
+    barrier; used to run the partitioned path against the unpartitioned one on a single GPU (or on CPU)."""
+
+    class _Shared:
+        def __init__(self, P):
+            self.P = P
+            self.barrier = threading.Barrier(P)
+            self.slots = [None] * P
+
+    def __init__(self, shared, rank):
+        self.s, self.rank, self.world_size = shared, rank, shared.P
+
+    @classmethod
+    def make(cls, P) -> List["ThreadComm"]:
+        sh = cls._Shared(P)
+        return [cls(sh, r) for r in range(P)]
+
+    def all_to_all(self, recv, send, recv_counts, send_counts):
+        if send.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.slots[self.rank] = (send, send_counts)
+        self.s.barrier.wait()
+        off = 0
+        for src in range(self.world_size):
+            n = recv_counts[src]
+            if n:
+                sbuf, scounts = self.s.slots[src]
+                s0 = sum(scounts[:self.rank])
+                recv[off:off + n].copy_(sbuf[s0:s0 + n])
+            off += n
+        if recv.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.slots[self.rank] = t.clone()
+        self.s.barrier.wait()
+        acc = self.s.slots[0].clone()
+        for r in range(1, self.world_size):
+            acc += self.s.slots[r]
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.barrier.wait()
+        t.copy_(acc)
+        return t
+
+    def barrier(self):
+        self.s.barrier.wait()
+
+
+# ------------------------------------------------------------------------------------ distributed nets
+def global_csr(edge_index: np.ndarray, n: int):
+    return ops.csr_build_host(edge_index, n)
+
+
+class ShardedData:
+    """What a rank's two engines read: local slices of the static inputs + the two halo plans."""
+
+    def __init__(self, dataset, n_mesh, rank: int, P: int, face_owner=None):
+        V, F = len(n_mesh.vs), len(n_mesh.faces)
+        if face_owner is None:
+            face_owner = face_owner_morton(n_mesh.fc, P)
+        self.face_owner = face_owner
+        self.vert_owner = vertex_owner_from_faces(n_mesh.faces, face_owner, V)
+        ei = dataset.edge_index.cpu().numpy()
+        fi = dataset.face_index.cpu().numpy()
+        self.vplan = HaloPlan(*global_csr(ei, V), self.vert_owner, rank, P)
+        self.fplan = HaloPlan(*global_csr(fi, F), self.face_owner, rank, P)
+        self.z1 = dataset.z1.detach().cpu()[torch.from_numpy(self.vplan.local_ids)]
+        self.z2 = dataset.z2.detach().cpu()[torch.from_numpy(self.fplan.local_ids)]
+        self.x_pos = dataset.x_pos.detach().cpu()[torch.from_numpy(self.vplan.owned)]
+        self.V, self.F = V, F
+
+
+class DistributedTrainer:
+    """main.py:88-110 on P ranks (see module docstring)."""
+
+    def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
+                 k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
+                 bnf_start_epoch=100, ops_mod=None, loss_engine=None):
+        from .engine import GcnEngine, POS_WIDTHS, NORM_WIDTHS
+        self.ops = ops_mod or ops
+        self.backend, self.device = backend, device
+        self.posnet, self.normnet = posnet, normnet
+        sd = sharded
+        self.sd = sd
+        vg = self.ops.Graph.from_csr_host(sd.vplan.rowptr, sd.vplan.col, sd.vplan.dinv, sd.vplan.n_cols)
+        fg = self.ops.Graph.from_csr_host(sd.fplan.rowptr, sd.fplan.col, sd.fplan.dinv, sd.fplan.n_cols)
+        self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
+                              comm=GraphComm(backend, sd.vplan, device), n_total=sd.V)
+        self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
+                              comm=GraphComm(backend, sd.fplan, device), n_total=sd.F)
+        posnet._engine, normnet._engine = self.peng, self.neng
+        self.owned_v = torch.from_numpy(sd.vplan.owned).to(device)
+        self.owned_f = torch.from_numpy(sd.fplan.owned).to(device)
+        self.full = torch.zeros((sd.V + sd.F, 3), dtype=torch.float32, device=device)
+        if loss_engine is None:
+            from .loss import LossEngine
+            loss_engine = LossEngine(n_mesh, device, bnfloop=bnfloop, k=k)
+        self.loss_engine = loss_engine
+        self.pos_lr, self.norm_lr, self.grad_crip, self.betas, self.eps = pos_lr, norm_lr, grad_crip, betas, eps
+        self.bnf_start_epoch = bnf_start_epoch
+        self.m = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+        self.v = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+        self.epoch = 0
+        self.t = 0
+        self.lossbuf = None
+
+    def barrier(self):
+        self.backend.barrier()
+
+    def gather_pos(self):
+        return self.full[: self.sd.V]
+
+    @torch.no_grad()
+    def step(self):
+        o = self.ops
+        self.epoch += 1
+        self.t += 1
+        V = self.sd.V
+        pa, na = self.posnet.arena.data, self.normnet.arena.data
+        pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
+        pos_loc = self.peng.forward(pa, update_running=True)
+        norm_loc = self.neng.forward(na, update_running=True)
+        self.full.zero_()
+        self.full[:V].index_copy_(0, self.owned_v, pos_loc)
+        self.full[V:].index_copy_(0, self.owned_f, norm_loc)
+        self.backend.all_reduce_sum(self.full)
+        pos, norm = self.full[:V], self.full[V:]
+        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
+        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
+        self.peng.backward(pa, pg, dpos.index_select(0, self.owned_v))
+        self.neng.backward(na, ng, dnorm.index_select(0, self.owned_f))
+        self.posnet._reduce_grads()
+        self.normnet._reduce_grads()
+        o.grad_sumsq(ng, out=self.sumsq)
+        o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+        o.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
+                     clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        self.lossbuf = lossbuf
+        self.pos, self.norm = pos, norm
+        return lossbuf[5]
+
+
+def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnfloop=1, backend=None, nets=None, **kw):
+    from .networks import PosNet, NormalNet
+    backend = backend or TorchDistComm()
+    if nets is None:
+        torch.manual_seed(0)                   # identical initial parameters on every rank
+        nets = (PosNet(device), NormalNet(device))
+    posnet, normnet = nets
+    sharded = ShardedData(dataset, n_mesh, rank, world)
+    return DistributedTrainer(posnet, normnet, sharded, n_mesh, backend, device, bnfloop=bnfloop, **kw)

@@ -1,0 +1,205 @@
+"""Multi-device host logic on CPU: partitioner / halo plans, the engine's layer loop over a partitioned graph
+with real collectives (gloo, world_size 2) and with threaded logical ranks, against the unpartitioned run.
+Compute is the torch-CPU stand-in of tests/cpu_ops_stub.py (no HIP kernel can run here)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _mesh(kind="ico2"):
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    v, f = synth.icosphere(2) if kind == "ico2" else synth.open_grid(9, 7)
+    v, f = synth.permute_vertices(v, f, 2)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    return noisy, smooth, dataset_from_meshes(noisy, smooth)
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+@pytest.mark.parametrize("kind", ["ico2", "grid"])
+def test_halo_plans_are_consistent(P, kind):
+    from dual_dmp_amd import dist as D, ops
+    noisy, smooth, data = _mesh(kind)
+    F, V = len(noisy.faces), len(noisy.vs)
+    fo = D.face_owner_morton(noisy.fc, P)
+    assert np.bincount(fo, minlength=P).min() >= F // P - 1 and np.bincount(fo, minlength=P).max() <= F // P + 1
+    vo = D.vertex_owner_from_faces(noisy.faces, fo, V)
+    for owner, ei, n in ((fo, data.face_index.numpy(), F), (vo, data.edge_index.numpy(), V)):
+        rowptr, col, dinv = ops.csr_build_host(ei, n)
+        plans = [D.HaloPlan(rowptr, col, dinv, owner, r, P) for r in range(P)]
+        assert sorted(np.concatenate([p.owned for p in plans]).tolist()) == list(range(n))
+        for r, p in enumerate(plans):
+            # halo == exactly the non-owned neighbours of owned rows
+            nb = set()
+            for i in p.owned:
+                nb.update(col[rowptr[i]:rowptr[i + 1]].tolist())
+            assert set(p.halo.tolist()) == {j for j in nb if owner[j] != r}
+            # local CSR maps back to the global one, row by row, in the same order
+            for li, i in enumerate(p.owned):
+                loc = p.local_ids[p.col[p.rowptr[li]:p.rowptr[li + 1]]]
+                assert np.array_equal(loc, col[rowptr[i]:rowptr[i + 1]])
+            assert np.array_equal(p.dinv, dinv[p.local_ids])
+            # what r receives from s is what s sends to r, in the same order
+            off = 0
+            for s in range(P):
+                cnt = p.recv_counts[s]
+                want = p.halo[off:off + cnt]
+                q = plans[s]
+                s0 = sum(q.send_counts[:r])
+                assert q.send_counts[r] == cnt
+                assert np.array_equal(q.owned[q.send_idx[s0:s0 + cnt]], want)
+                off += cnt
+
+
+def _reference_run(noisy, smooth, data, steps, stub, oracle):
+    """Unpartitioned run with the same stub arithmetic."""
+    from dual_dmp_amd import engine
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    torch.manual_seed(0)
+    posnet, normnet = PosNet("cpu"), NormalNet("cpu")
+    k = (3.0, 4.0, 4.0, 4.0, 1.0)
+    tr = FusedTrainer.__new__(FusedTrainer)
+    # assemble a FusedTrainer by hand around the stub (its __init__ would build the HIP LossEngine)
+    tr.posnet, tr.normnet, tr.dataset, tr.device = posnet, normnet, data, torch.device("cpu")
+    tr.pos_lr = tr.norm_lr = 0.01
+    tr.grad_crip, tr.betas, tr.eps, tr.bnf_start_epoch = 0.8, (0.9, 0.999), 1e-8, 100
+    tr.loss_engine = stub.OracleLossEngine(oracle, noisy, k, 1)
+    tr.peng, tr.neng = posnet._get_engine(data), normnet._get_engine(data)
+    tr.m = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+    tr.v = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+    tr.sumsq = torch.zeros(1, dtype=torch.float64)
+    tr.epoch = tr.t = 0
+    out = []
+    for _ in range(steps):
+        loss = float(tr.step())
+        out.append((loss, tr.pos.clone(), tr.norm.clone()))
+    return out, posnet, normnet
+
+
+def _patch(monkeypatch_setattr, stub):
+    from dual_dmp_amd import engine, trainer, networks
+    monkeypatch_setattr(engine, "ops", stub)
+    monkeypatch_setattr(trainer, "ops", stub)
+    monkeypatch_setattr(networks, "ops", stub)
+
+
+def _rank_run(rank, P, backend, noisy, smooth, data, steps, stub, oracle, results, nets=None):
+    from dual_dmp_amd import dist as D
+    tr = D.make_distributed_trainer(noisy, smooth, data, torch.device("cpu"), rank, P, backend=backend, ops_mod=stub,
+                                    nets=nets,
+                                    loss_engine=stub.OracleLossEngine(oracle, noisy, (3.0, 4.0, 4.0, 4.0, 1.0), 1))
+    out = []
+    for _ in range(steps):
+        loss = float(tr.step())
+        out.append((loss, tr.pos.clone(), tr.norm.clone()))
+    results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone())
+
+
+def _compare(ref, got, ref_nets, tag):
+    ref_hist, posnet, normnet = ref_nets
+    for s, ((l0, p0, n0), (l1, p1, n1)) in enumerate(zip(ref_hist, got[0])):
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (tag, s, l0, l1)
+        assert float((p0 - p1).abs().max()) < 2e-5, (tag, s)
+        assert float((n0 - n1).abs().max()) < 2e-5, (tag, s)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P):
+    import cpu_ops_stub as stub
+    from dual_dmp_amd import dist as D
+    _patch(monkeypatch.setattr, stub)
+    noisy, smooth, data = _mesh("ico2")
+    ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
+    comms = D.ThreadComm.make(P)
+    results = {}
+    errs = []
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    nets = []
+    for _ in range(P):                      # threads share the global RNG: initialise the replicas serially
+        torch.manual_seed(0)
+        nets.append((PosNet("cpu"), NormalNet("cpu")))
+
+    def work(r):
+        try:
+            _rank_run(r, P, comms[r], noisy, smooth, data, 2, stub, oracle, results, nets=nets[r])
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            comms[r].s.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for r in range(P):
+        _compare(ref[0], results[r], ref, "rank%d" % r)
+        # parameters stay replicated
+        assert torch.equal(results[r][1], results[0][1]) and torch.equal(results[r][2], results[0][2])
+    # and equal to the single-rank parameters up to summation order (conv biases excluded: their gradient is
+    # analytically zero after BatchNorm, Adam turns its rounding noise into +-lr steps)
+    lay = ref[1].layout
+    bad = tot = 0
+    for name, *_ in lay.entries:
+        if name.startswith("conv") and name.endswith(".bias"):
+            continue
+        d = (lay.view(results[0][1], name) - lay.view(ref[1].arena.detach(), name)).abs()
+        bad += int((d > 1e-4).sum())
+        tot += d.numel()
+    assert bad <= 1e-3 * tot, (bad, tot)
+
+
+def _gloo_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, HERE)
+        sys.path.insert(0, os.path.dirname(HERE))
+        import cpu_ops_stub as stub
+        from conftest import load_oracle
+        from dual_dmp_amd import engine, trainer, networks, dist as D
+        for mod in (engine, trainer, networks):
+            mod.ops = stub
+        oracle = load_oracle()
+        noisy, smooth, data = _mesh("ico2")
+        results = {}
+        _rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, oracle, results)
+        out, pa, na = results[rank]
+        q.put((rank, [(l, p.numpy(), n.numpy()) for l, p, n in out], pa.numpy(), na.numpy()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:          # noqa: BLE001
+        q.put((rank, repr(e), None, None))
+        raise
+
+
+def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle):
+    """The real torch.distributed code path (all_to_all_single halo exchange, all_reduce of BN sums / gradients /
+    pos+norm) with world_size 2 over gloo."""
+    import torch.multiprocessing as mp
+    import cpu_ops_stub as stub
+    _patch(monkeypatch.setattr, stub)
+    noisy, smooth, data = _mesh("ico2")
+    ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = {}
+    for _ in range(2):
+        rank, out, pa, na = q.get(timeout=300)
+        assert pa is not None, out
+        got[rank] = ([(l, torch.from_numpy(p), torch.from_numpy(n)) for l, p, n in out], pa, na)
+    [p.join(60) for p in procs]
+    for r in range(2):
+        _compare(ref[0], got[r], ref, "gloo rank%d" % r)
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
