@@ -156,8 +156,8 @@ def main():
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
 
-    comm = None
-    if world > 1:
+    force_dist = os.environ.get("DDMP_FORCE_DIST") == "1"      # exercise the RCCL path at world_size 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -166,7 +166,7 @@ def main():
     gt, noisy, smooth, data = build_case(args.faces, args.order)
     V, F = len(noisy.vs), len(noisy.faces)
     torch.manual_seed(0)
-    if world > 1:
+    if world > 1 or force_dist:
         from dual_dmp_amd.dist import make_distributed_trainer
         tr = make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop)
         barrier = tr.barrier
@@ -187,7 +187,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,7 +199,7 @@ def main():
     if rank == 0:
         from dual_dmp_amd.loss import mad
         from dual_dmp_amd.mesh import Mesh
-        pos = tr.gather_pos().cpu().numpy() if world > 1 else tr.pos.cpu().numpy()
+        pos = tr.gather_pos().cpu().numpy() if (world > 1 or force_dist) else tr.pos.cpu().numpy()
         o = Mesh.__new__(Mesh)
         o.vs, o.faces = pos.astype(np.float64), noisy.faces
         Mesh.compute_face_normals(o)
@@ -255,7 +255,7 @@ def main():
             with open(args.kernel_table, "w") as fh:
                 json.dump({"config": line["config"], "ms_per_step": line["ms_per_step"], "kernels": table}, fh, indent=1)
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -22,6 +22,7 @@ optimised; their gradient is not computed here.
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -102,8 +103,10 @@ class _FusedNet(nn.Module):
 
     def _get_engine(self, data):
         x0, x_pos, edge_index = self._inputs(data)
-        key = (x0.data_ptr(), edge_index.data_ptr(), tuple(edge_index.shape), x0.shape[0])
-        if self._engine is None or self._engine_key != key:
+        key = self._engine_key
+        same = (self._engine is not None and key is not None and key[0]() is x0 and key[1]() is edge_index
+                and key[2] == (x0._version, edge_index._version))
+        if not same:
             dev = self.device
             graph = getattr(data, "_ddmp_graph_%d" % self._kind, None)
             if graph is None:
@@ -111,7 +114,7 @@ class _FusedNet(nn.Module):
             self._engine = GcnEngine(graph, self._widths, self._kind, x0.detach().to(dev),
                                      None if x_pos is None else x_pos.to(dev), comm=self.comm,
                                      n_total=getattr(data, "_ddmp_n_total_%d" % self._kind, None))
-            self._engine_key = key
+            self._engine_key = (weakref.ref(x0), weakref.ref(edge_index), (x0._version, edge_index._version))
             pend = getattr(self, "_pending_running", None)
             if pend:
                 for l in range(12):
@@ -171,6 +174,19 @@ class _ModularNet(nn.Module):
         self.l_relu = nn.LeakyReLU()
         self.to(self.device)
 
+    def _dev(self, data, name):
+        """Device copy of a dataset tensor, kept on the dataset (the reference re-uploads on every forward,
+        util/networks.py:49,110; a stable tensor object also lets the graph cache hit)."""
+        t = getattr(data, name)
+        if t.device == self.device:
+            return t
+        cache = data.__dict__.setdefault("_ddmp_dev", {})
+        hit = cache.get((name, str(self.device)))
+        if hit is None or hit[0] is not t or hit[1] != t._version:
+            hit = (t, t._version, t.detach().to(self.device))
+            cache[(name, str(self.device))] = hit
+        return hit[2]
+
     def _trunk(self, x, edge_index):
         for i in range(1, 13):
             x = self.l_relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(x, edge_index)))
@@ -181,7 +197,7 @@ class PosNetModular(_ModularNet):
     _widths = POS_WIDTHS
 
     def forward(self, data):
-        z1, x_pos, edge_index = data.z1.to(self.device), data.x_pos.to(self.device), data.edge_index.to(self.device)
+        z1, x_pos, edge_index = self._dev(data, "z1"), self._dev(data, "x_pos"), self._dev(data, "edge_index")
         dx = self._trunk(z1, edge_index)
         dx = self.linear2(self.l_relu(self.linear1(dx)))
         return x_pos + dx
@@ -191,7 +207,7 @@ class NormalNetModular(_ModularNet):
     _widths = NORM_WIDTHS
 
     def forward(self, data):
-        z2, edge_index = data.z2.to(self.device), data.face_index.to(self.device)
+        z2, edge_index = self._dev(data, "z2"), self._dev(data, "face_index")
         dx = self._trunk(z2, edge_index)
         dx = torch.tanh(self.linear2(self.l_relu(self.linear1(dx))))
         dx_norm = torch.reciprocal(torch.norm(dx, dim=1, keepdim=True).expand(-1, 3) + 1.0e-12)

@@ -143,15 +143,20 @@ _graph_cache = {}
 
 
 def graph_for(edge_index: torch.Tensor, num_nodes: int) -> Graph:
-    """Cache keyed on the edge_index storage + version (static mesh graph)."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), int(num_nodes),
-           str(edge_index.device))
-    g = _graph_cache.get(key)
-    if g is None:
-        if len(_graph_cache) > 16:
-            _graph_cache.clear()
-        g = Graph.from_edge_index(edge_index, num_nodes)
-        _graph_cache[key] = g
+    """Graph of a static mesh, cached on the IDENTITY of the edge_index tensor (weak reference + in-place
+    version counter).  A data_ptr key would be wrong: a freed tensor's address is reused by other meshes.
+    A caller that builds a fresh edge_index tensor on every call (as ``data.edge_index.to(device)`` does when
+    the dataset lives on the host) gets a correct but rebuilt graph each time -- keep the tensor."""
+    key = id(edge_index)
+    hit = _graph_cache.get(key)
+    if hit is not None:
+        ref, version, n, g = hit
+        if ref() is edge_index and version == edge_index._version and n == int(num_nodes):
+            return g
+    for k in [k for k, v in _graph_cache.items() if v[0]() is None]:
+        del _graph_cache[k]
+    g = Graph.from_edge_index(edge_index, num_nodes)
+    _graph_cache[key] = (weakref.ref(edge_index), edge_index._version, int(num_nodes), g)
     return g
 
 

@@ -193,6 +193,16 @@ int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, 
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
 
+/* ------------------------------------------------------------------ evaluation block (main.py:117-123)
+ * Face normals of predicted positions (util/mesh.py:87-92; float32 like the reference's float32 `new_pos`)
+ * and MAD = mean over faces of deg(arccos(clip(n1.n2, -1, 1))) in float64 (util/loss.py:261-272).
+ */
+int ddmp_face_normals_f32(int64_t F, const float* pos, const int32_t* faces, float* fn /*[F,3]*/,
+                          float* fa /*[F] nullable*/, ddmp_stream stream);
+size_t ddmp_mad_workspace_bytes(void);
+int ddmp_mad_f64(int64_t F, const float* n1 /*[F,3] f32*/, const double* n2 /*[F,3] f64*/, double* out /*[1]*/,
+                 void* workspace, size_t workspace_bytes, ddmp_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

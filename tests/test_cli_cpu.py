@@ -1,0 +1,89 @@
+"""Host-side pieces that need no GPU: C ABI surface, CLI flags, dataset assembly."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from dual_dmp_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    lib = _lib.lib()                       # resolves every prototype or raises
+    for name in protos:
+        assert hasattr(lib, name), name
+    assert lib.ddmp_abi_version() == 1
+    assert _lib.status_string(0) == "ok" and _lib.status_string(-4) == "workspace too small"
+    # argument validation happens before any device work
+    assert lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None) == -1
+    assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None) == -1
+    assert lib.ddmp_gemm_tn_workspace_bytes(1000000, 512, 512) > 0
+
+
+def test_host_csr_matches_gcn_norm(oracle):
+    from dual_dmp_amd import ops, synth
+    from dual_dmp_amd.mesh import Mesh
+    v, f = synth.open_grid(6, 5)
+    m = Mesh(vs=v, faces=f)
+    e = torch.tensor(m.edges.T, dtype=torch.long)
+    ei = torch.cat([e, e[[1, 0]], torch.tensor([[0, 3], [0, 3]])], 1)          # + two explicit self loops
+    n = len(v)
+    rowptr, col, dinv = ops.csr_build_host(ei.numpy(), n)
+    keep = ei[:, ei[0] != ei[1]]
+    row, colo, w = oracle.gcn_norm(keep, n, torch.float64)
+    deg = torch.zeros(n, dtype=torch.float64).scatter_add_(0, colo, torch.ones_like(w))
+    np.testing.assert_allclose(dinv, deg.pow(-0.5).numpy(), rtol=1e-7)
+    for i in range(n):
+        want = sorted(keep[0][keep[1] == i].tolist() + [i])
+        assert col[rowptr[i]:rowptr[i + 1]].tolist() == want
+    order = ops.bfs_order_host(rowptr, col)
+    assert sorted(order.tolist()) == list(range(n))
+    with pytest.raises(Exception):
+        ops.csr_build_host(np.array([[0, 99], [1, 2]]), n)
+
+
+def test_cli_flags_match_reference_defaults():
+    from dual_dmp_amd.cli import get_parser
+    a = get_parser(False).parse_args(["-i", "x"])
+    assert (a.pos_lr, a.norm_lr, a.iter, a.k1, a.k2, a.k3, a.k4, a.k5, a.grad_crip, a.bnfloop, a.gpu, a.port) == \
+           (0.01, 0.01, 1000, 3.0, 4.0, 4.0, 4.0, 1.0, 0.8, 1, 0, 8080)
+    assert a.norm_optim == "Adam" and a.viewer is True
+    r = get_parser(True).parse_args(["-i", "x"])
+    assert (r.k1, r.k2, r.k3, r.k4, r.k5, r.bnfloop) == (3.0, 0.0, 3.0, 4.0, 2.0, 5)
+    with pytest.raises(SystemExit):
+        get_parser(False).parse_args([])
+
+
+def test_create_dataset_from_directory(tmp_path, oracle):
+    from dual_dmp_amd import synth, datamaker
+    gt, noisy, smooth = synth.make_triplet(*synth.icosphere(1))
+    d = synth.write_dataset_dir(str(tmp_path), "ball", gt, noisy, smooth)
+    mesh_dic, ds = datamaker.create_dataset(d)
+    assert mesh_dic["mesh_name"] == "ball" and mesh_dic["gt_mesh"] is not None
+    n_mesh, s_mesh = mesh_dic["n_mesh"], mesh_dic["s_mesh"]
+    V, F, E = len(n_mesh.vs), len(n_mesh.faces), n_mesh.edges_count
+    assert ds.z1.shape == (V, 16) and ds.z1.dtype == torch.float32 and ds.z2.shape == (F, 7)
+    assert ds.edge_index.shape == (2, 2 * E) and ds.edge_index.dtype == torch.int64
+    assert ds.face_index.shape == (2, 3 * F)
+    assert (ds.num_nodes, ds.num_edges, ds.num_node_features) == (V, 2 * E, 16)
+    assert not ds.contains_isolated_nodes and not ds.contains_self_loops
+    od = oracle.OracleDataset(n_mesh, s_mesh)
+    for k in ("z1", "z2", "x_pos", "x_norm", "edge_index", "face_index"):
+        assert torch.equal(getattr(ds, k), getattr(od, k)), k
+    np.random.seed(314)
+    assert np.allclose(ds.z1.numpy(), np.random.normal(size=(V, 16)).astype(np.float32))
+    # without ground truth (main4real.py)
+    os.remove(os.path.join(d, "ball_gt.obj"))
+    assert datamaker.create_dataset(d)[0]["gt_mesh"] is None
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under dual-dmp_amd/ may reference it."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dual-dmp_amd")
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "ddmp_oracle" not in txt and "oracle/" not in txt.replace("oracle/README", ""), f

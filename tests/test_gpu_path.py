@@ -386,3 +386,33 @@ def test_reference_loop_shape_on_our_modules(dev, oracle):
         if epoch == 101:
             assert float((pos.detach().cpu() - ref_pos).abs().max()) < 2e-4
             assert float((norm.detach().cpu() - ref_norm).abs().max()) < 2e-4
+
+
+# ------------------------------------------------------------------------------------ evaluation + CLI
+@pytest.mark.parametrize("name", NAMES)
+def test_device_evaluator_matches_reference_golden(dev, golden_dir, name):
+    """Face normals + MAD on the device vs Mesh.compute_face_normals / Loss.mad of the reference (golden)."""
+    from dual_dmp_amd.evaluate import Evaluator
+    gl = np.load(os.path.join(golden_dir, "loss_%s.npz" % name))
+    m = _golden_mesh(golden_dir, name)
+    ev = Evaluator(m, m.fn, dev)
+    pos = torch.from_numpy(gl["pos"]).to(dev)
+    fn = ev.face_normals(pos).cpu().numpy()
+    np.testing.assert_allclose(fn, gl["cfn_fn"], atol=2e-6)            # f32 arithmetic vs the f64 golden
+    assert abs(ev.mad(pos) - float(gl["mad_pos"])) < 1e-3             # degrees
+
+
+def test_cli_runs_like_the_reference(dev, tmp_path, monkeypatch, capsys):
+    from dual_dmp_amd import synth, cli
+    gt, noisy, smooth = synth.make_triplet(*synth.icosphere(2))
+    d = synth.write_dataset_dir(str(tmp_path), "ball", gt, noisy, smooth)
+    monkeypatch.chdir(tmp_path)
+    tr = cli.run(["-i", d, "--iter", "20", "--seed", "0"], real=False)
+    out = capsys.readouterr().out
+    assert "initial_mad:" in out and "final_mad:" in out and "k1          : 3.0" in out
+    assert tr.epoch == 20
+    tr = cli.run(["-i", d, "--iter", "10", "--seed", "0"], real=True)
+    assert os.path.exists(tmp_path / "datasets" / "ball" / "output" / "10_ddmp.obj")
+    from dual_dmp_amd.mesh import Mesh
+    o = Mesh(str(tmp_path / "datasets" / "ball" / "output" / "10_ddmp.obj"))
+    assert np.array_equal(o.faces, noisy.faces) and np.allclose(o.vs, tr.pos.cpu().numpy(), atol=1e-6)
