@@ -17,6 +17,7 @@
 #include "ddmp_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -56,64 +57,65 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(
     // staging assignment: thread -> (k quad, row) ; 8 quads per row, 32 rows per pass
     const int kq = tid & 7, rr = tid >> 3;
     float4 ra[4], rb[(B_KMAJOR ? 4 : BN / 32)];
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // unconditional clamped loads (all in flight together); prologue + zero-masking at LDS-store time
     auto load_tiles = [&](int k0) {
-        const int kcol = k0 + kq * 4;
-        float4 sc, sh;
-        if (PRO && kcol < KD) {
-            sc = *reinterpret_cast<const float4*>(pscale + kcol);
-            sh = *reinterpret_cast<const float4*>(pshift + kcol);
+        const int kcol = min(k0 + kq * 4, KD - 4);
+        if (PRO) {
+            psc = *reinterpret_cast<const float4*>(pscale + kcol);
+            psh = *reinterpret_cast<const float4*>(pshift + kcol);
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int r = row0 + p * 32 + rr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < n_rows && kcol < KD) {
-                v = *reinterpret_cast<const float4*>(A + (int64_t)r * lda + kcol);
-                if (PRO) v = f4_affine_lrelu(v, sc, sh, slope);
-            }
-            ra[p] = v;
+            const int r = min(row0 + p * 32 + rr, n_rows - 1);
+            ra[p] = *reinterpret_cast<const float4*>(A + (int64_t)r * lda + kcol);
         }
         if (!B_KMAJOR) {
 #pragma unroll
             for (int p = 0; p < BN / 32; ++p) {
-                const int m = col0 + p * 32 + rr;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < MD && kcol < KD) v = *reinterpret_cast<const float4*>(B + (int64_t)m * ldb + kcol);
-                rb[p] = v;
+                const int m = min(col0 + p * 32 + rr, MD - 1);
+                rb[p] = *reinterpret_cast<const float4*>(B + (int64_t)m * ldb + kcol);
             }
         } else {
-            // B[k][m]: thread -> (m quad, k row): BN/4 quads per k row
             constexpr int QPR = BN / 4, KPP = 256 / QPR, NP = kBK / KPP;
             static_assert(NP <= 4, "rb too small");
             const int mq = tid % QPR, kr = tid / QPR;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const int k = k0 + p * KPP + kr, m = col0 + mq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < KD && m < MD) v = *reinterpret_cast<const float4*>(B + (int64_t)k * ldb + m);
-                rb[p] = v;
+                const int k = min(k0 + p * KPP + kr, KD - 1), m = min(col0 + mq * 4, ((MD + 3) / 4) * 4 - 4);
+                rb[p] = *reinterpret_cast<const float4*>(B + (int64_t)k * ldb + m);
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int k0) {
+        const bool kok = k0 + kq * 4 < KD;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<float4*>(&As[buf][(p * 32 + rr) * kLd + kq * 4]) = ra[p];
+        for (int p = 0; p < 4; ++p) {
+            float4 v = ra[p];
+            if (PRO) v = f4_affine_lrelu(v, psc, psh, slope);
+            if (!(kok && row0 + p * 32 + rr < n_rows)) v = zero4;
+            *reinterpret_cast<float4*>(&As[buf][(p * 32 + rr) * kLd + kq * 4]) = v;
+        }
         if (!B_KMAJOR) {
 #pragma unroll
-            for (int p = 0; p < BN / 32; ++p)
-                *reinterpret_cast<float4*>(&Bs[buf][(p * 32 + rr) * kLd + kq * 4]) = rb[p];
+            for (int p = 0; p < BN / 32; ++p) {
+                float4 v = rb[p];
+                if (!(kok && col0 + p * 32 + rr < MD)) v = zero4;
+                *reinterpret_cast<float4*>(&Bs[buf][(p * 32 + rr) * kLd + kq * 4]) = v;
+            }
         } else {
             constexpr int QPR = BN / 4, KPP = 256 / QPR, NP = kBK / KPP;
             const int mq = tid % QPR, kr = tid / QPR;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int k = p * KPP + kr;
-                Bs[buf][(mq * 4 + 0) * kLd + k] = rb[p].x;
-                Bs[buf][(mq * 4 + 1) * kLd + k] = rb[p].y;
-                Bs[buf][(mq * 4 + 2) * kLd + k] = rb[p].z;
-                Bs[buf][(mq * 4 + 3) * kLd + k] = rb[p].w;
+                const bool ok = (k0 + k < KD) && (col0 + mq * 4 < MD);
+                Bs[buf][(mq * 4 + 0) * kLd + k] = ok ? rb[p].x : 0.f;
+                Bs[buf][(mq * 4 + 1) * kLd + k] = ok ? rb[p].y : 0.f;
+                Bs[buf][(mq * 4 + 2) * kLd + k] = ok ? rb[p].z : 0.f;
+                Bs[buf][(mq * 4 + 3) * kLd + k] = ok ? rb[p].w : 0.f;
             }
         }
     };
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(
 
     const int nk = (KD + kBK - 1) / kBK;
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        if (kt + 1 < nk) store_tiles(buf ^ 1, (kt + 1) * kBK);
         __syncthreads();
     }
 
@@ -213,27 +215,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
         sh = *reinterpret_cast<const float4*>(pshift + zc);
     }
     float4 rg[NP], rz[NP];
+    const int gcl = min(gc, ((M + 3) / 4) * 4 - 4), zcl = min(zc, ((K + 3) / 4) * 4 - 4);
     auto load_tiles = [&](int r0) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int r = r0 + p * RPP + pr;
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f), z = g;
-            if (r < r_end) {
-                if (gc < M) g = *reinterpret_cast<const float4*>(G + (int64_t)r * ldg + gc);
-                if (zc < K) {
-                    z = *reinterpret_cast<const float4*>(Z + (int64_t)r * ldz + zc);
-                    if (PRO) z = f4_affine_lrelu(z, sc, sh, slope);
-                }
-            }
-            rg[p] = g;
-            rz[p] = z;
+            const int r = min(r0 + p * RPP + pr, r_end - 1);
+            rg[p] = *reinterpret_cast<const float4*>(G + (int64_t)r * ldg + gcl);
+            rz[p] = *reinterpret_cast<const float4*>(Z + (int64_t)r * ldz + zcl);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int r0) {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            *reinterpret_cast<float4*>(&Gs[buf][(p * RPP + pr) * BT + q * 4]) = rg[p];
-            *reinterpret_cast<float4*>(&Zs[buf][(p * RPP + pr) * BT + q * 4]) = rz[p];
+            const bool rok = r0 + p * RPP + pr < r_end;
+            float4 z = rz[p];
+            if (PRO) z = f4_affine_lrelu(z, sc, sh, slope);
+            *reinterpret_cast<float4*>(&Gs[buf][(p * RPP + pr) * BT + q * 4]) = (rok && gc < M) ? rg[p] : zero4;
+            *reinterpret_cast<float4*>(&Zs[buf][(p * RPP + pr) * BT + q * 4]) = (rok && zc < K) ? z : zero4;
         }
     };
 
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
     const int nt = (r_end - r_begin + 31) / 32;
     if (nt > 0) {
         load_tiles(r_begin);
-        store_tiles(0);
+        store_tiles(0, r_begin);
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(
                 for (int j = 0; j < T; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nt) store_tiles(buf ^ 1);
+        if (t + 1 < nt) store_tiles(buf ^ 1, r_begin + (t + 1) * 32);
         __syncthreads();
     }
 
@@ -335,7 +334,26 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
     return p;
 }
 
+#include "gemm_bf16x.inc"
+
 }  // namespace
+
+// GEMM arithmetic: 6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA
+static int g_gemm_mode = -1;
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("DDMP_GEMM_MODE");
+        int m = e ? atoi(e) : 6;
+        g_gemm_mode = (m == 0 || m == 3 || m == 6) ? m : 6;
+    }
+    return g_gemm_mode;
+}
+extern "C" int ddmp_set_gemm_mode(int mode) {
+    if (mode != 0 && mode != 3 && mode != 6) return DDMP_EINVAL;
+    g_gemm_mode = mode;
+    return DDMP_OK;
+}
+extern "C" int ddmp_get_gemm_mode(void) { return gemm_mode(); }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -353,14 +371,22 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int TN = M > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
-#define DDMP_LAUNCH_NT(TN_, PRO_)                                                                       \
-    hipLaunchKernelGGL((gemm_rows_kernel<TN_, false, PRO_>), grid, block, 0, st, A, lda, W, ldw, Y, ldy, \
-                       (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, n_row_tiles, n_col_tiles)
+#define DDMP_LAUNCH_NT(KERNEL_, PRO_)                                                                    \
+    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, W, ldw, Y, ldy, (int)n_rows, K, M, bias, \
+                       pro_scale, pro_shift, slope, n_row_tiles, n_col_tiles)
+#define DDMP_NT_BY_MODE(TN_, PRO_)                                                          \
+    do {                                                                                    \
+        const int mode_ = gemm_mode();                                                      \
+        if (mode_ == 6) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, 3, false, PRO_>), PRO_); \
+        else if (mode_ == 3) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, 2, false, PRO_>), PRO_); \
+        else DDMP_LAUNCH_NT((gemm_rows_kernel<TN_, false, PRO_>), PRO_);                    \
+    } while (0)
     if (TN == 2) {
-        if (pro_scale) DDMP_LAUNCH_NT(2, true); else DDMP_LAUNCH_NT(2, false);
+        if (pro_scale) DDMP_NT_BY_MODE(2, true); else DDMP_NT_BY_MODE(2, false);
     } else {
-        if (pro_scale) DDMP_LAUNCH_NT(1, true); else DDMP_LAUNCH_NT(1, false);
+        if (pro_scale) DDMP_NT_BY_MODE(1, true); else DDMP_NT_BY_MODE(1, false);
     }
+#undef DDMP_NT_BY_MODE
 #undef DDMP_LAUNCH_NT
     LAUNCH_TRY();
     return DDMP_OK;
@@ -377,12 +403,20 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     const int TN = K > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(K, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
-    if (TN == 2)
-        hipLaunchKernelGGL((gemm_rows_kernel<2, true, false>), grid, block, 0, st, A, lda, W, ldw, Y, ldy,
-                           (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles);
-    else
-        hipLaunchKernelGGL((gemm_rows_kernel<1, true, false>), grid, block, 0, st, A, lda, W, ldw, Y, ldy,
-                           (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles);
+#define DDMP_LAUNCH_NN(KERNEL_)                                                                        \
+    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, W, ldw, Y, ldy, (int)n_rows, M, K, nullptr, \
+                       nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles)
+    const int mode = gemm_mode();
+    if (TN == 2) {
+        if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 3, true, false>));
+        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 2, true, false>));
+        else DDMP_LAUNCH_NN((gemm_rows_kernel<2, true, false>));
+    } else {
+        if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 3, true, false>));
+        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 2, true, false>));
+        else DDMP_LAUNCH_NN((gemm_rows_kernel<1, true, false>));
+    }
+#undef DDMP_LAUNCH_NN
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -410,15 +444,22 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
     dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(256);
-#define DDMP_LAUNCH_TN(T_, PRO_)                                                                          \
-    hipLaunchKernelGGL((gemm_tn_kernel<T_, PRO_>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K,  \
-                       sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, \
-                       pro_scale, pro_shift, slope)
+#define DDMP_LAUNCH_TN(KERNEL_)                                                                           \
+    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride, (int)n_rows, \
+                       M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope)
+#define DDMP_TN_BY_MODE(T_, PRO_)                                                 \
+    do {                                                                          \
+        const int mode_ = gemm_mode();                                            \
+        if (mode_ == 6) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 3, PRO_>));       \
+        else if (mode_ == 3) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 2, PRO_>));  \
+        else DDMP_LAUNCH_TN((gemm_tn_kernel<T_, PRO_>));                          \
+    } while (0)
     if (p.T == 2) {
-        if (pro_scale) DDMP_LAUNCH_TN(2, true); else DDMP_LAUNCH_TN(2, false);
+        if (pro_scale) DDMP_TN_BY_MODE(2, true); else DDMP_TN_BY_MODE(2, false);
     } else {
-        if (pro_scale) DDMP_LAUNCH_TN(1, true); else DDMP_LAUNCH_TN(1, false);
+        if (pro_scale) DDMP_TN_BY_MODE(1, true); else DDMP_TN_BY_MODE(1, false);
     }
+#undef DDMP_TN_BY_MODE
 #undef DDMP_LAUNCH_TN
     LAUNCH_TRY();
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part,

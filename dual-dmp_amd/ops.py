@@ -70,6 +70,15 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def set_gemm_mode(mode: int):
+    """6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA."""
+    check(_lib.lib().ddmp_set_gemm_mode(int(mode)), "ddmp_set_gemm_mode")
+
+
+def get_gemm_mode() -> int:
+    return int(_lib.lib().ddmp_get_gemm_mode())
+
+
 def _chk(t, dtype=torch.float32, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise DdmpError("%s must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback" % name)

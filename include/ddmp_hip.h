@@ -91,6 +91,12 @@ int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, f
 int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
                      int64_t n_rows, int M, int K, ddmp_stream stream);
 size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
+/* GEMM arithmetic: 6 = bf16x6 split MFMA (default: every f32 operand is split into three bf16 terms, six
+ * bf16 MFMA products accumulated in f32 -- f32-class accuracy at 2.67x the f32-MFMA rate), 3 = bf16x3
+ * (three products, ~2^-16 relative), 0 = f32-input MFMA (v_mfma_f32_32x32x2_f32).  Process-wide; the
+ * environment variable DDMP_GEMM_MODE sets the initial value. */
+int ddmp_set_gemm_mode(int mode);
+int ddmp_get_gemm_mode(void);
 int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW, int64_t lddw,
                      int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift,
                      float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream);

@@ -90,28 +90,43 @@ def test_spmm_multi_edges_and_self_loops(dev):
     assert relerr(y, dense_ahat(keep, n) @ x.double()) < 1e-6
 
 
+@pytest.fixture(params=[6, 3, 0], ids=["bf16x6", "bf16x3", "f32mfma"])
+def gemm_mode(request):
+    """Every GEMM arithmetic of the library: the default bf16x6 split MFMA (f32-class accuracy), bf16x3
+    (three products, ~2^-16 per product) and the f32-input MFMA kernels."""
+    from dual_dmp_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(request.param)
+    yield request.param
+    ops.set_gemm_mode(old)
+
+
+GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6}
+
+
 @pytest.mark.parametrize("n,K,M", [(1000, 32, 64), (777, 512, 512), (130, 8, 32), (513, 256, 128),
                                    (300, 16, 32), (2000, 64, 32), (129, 128, 256), (50, 32, 3)])
-def test_gemm_nt_nn_tn(dev, n, K, M):
+def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
     from dual_dmp_amd import ops
+    tol = GEMM_TOL[gemm_mode]
     torch.manual_seed(n + K + M)
     a, w, bias = torch.randn(n, K), torch.randn(M, K) / K ** 0.5, torch.randn(M)
     sc, sh = torch.rand(K) + 0.5, torch.randn(K)
     y = ops.gemm_nt(a.to(dev), w.to(dev), bias=bias.to(dev))
-    assert relerr(y, a.double() @ w.double().t() + bias.double()) < 2e-6
+    assert relerr(y, a.double() @ w.double().t() + bias.double()) < tol
     y = ops.gemm_nt(a.to(dev), w.to(dev), pro=(sc.to(dev), sh.to(dev)))
-    assert relerr(y, f_ref(a.double(), sc.double(), sh.double()) @ w.double().t()) < 2e-6
+    assert relerr(y, f_ref(a.double(), sc.double(), sh.double()) @ w.double().t()) < tol
     if M % 4 == 0:
         g = torch.randn(n, M)
         dx = ops.gemm_nn(g.to(dev), w.to(dev))
-        assert relerr(dx, g.double() @ w.double()) < 2e-6
+        assert relerr(dx, g.double() @ w.double()) < tol
         dw = ops.gemm_tn(g.to(dev), a.to(dev))
-        assert relerr(dw, g.double().t() @ a.double()) < 2e-6
+        assert relerr(dw, g.double().t() @ a.double()) < tol
         dw = ops.gemm_tn(g.to(dev), a.to(dev), pro=(sc.to(dev), sh.to(dev)))
-        assert relerr(dw, g.double().t() @ f_ref(a.double(), sc.double(), sh.double())) < 2e-6
+        assert relerr(dw, g.double().t() @ f_ref(a.double(), sc.double(), sh.double())) < tol
 
 
-def test_gemm_transpose_detecting(dev):
+def test_gemm_transpose_detecting(dev, gemm_mode):
     """A = I with an asymmetric W: a swapped C-write would show."""
     from dual_dmp_amd import ops
     n = 128

@@ -339,9 +339,12 @@ def test_training_free_running_within_reference_noise_floor(dev, oracle, bnfloop
         floor_p = max(floor_p, float((p32.double() - p64).abs().max()))
         floor_n = max(floor_n, float((n32.double() - n64).abs().max()))
         floor_l = max(floor_l, abs(l32 - l64) / l64)
-        assert float((tr.pos.cpu().double() - p64).abs().max()) <= 10 * floor_p + 1e-5, s
-        assert float((tr.norm.cpu().double() - n64).abs().max()) <= 10 * floor_n + 1e-5, s
-        assert abs(loss - l64) / l64 <= 10 * floor_l + 1e-5, s
+        # strict while the error is still in the linear regime (iterations 1-3: a reduced-precision GEMM such as
+        # bf16x3 starts 26x above the floor and fails here); afterwards both runs saturate towards O(1)
+        fac = 10 if s < 3 else 100
+        assert float((tr.pos.cpu().double() - p64).abs().max()) <= fac * floor_p + 1e-5, s
+        assert float((tr.norm.cpu().double() - n64).abs().max()) <= fac * floor_n + 1e-5, s
+        assert abs(loss - l64) / l64 <= fac * floor_l + 1e-5, s
 
 
 def test_reference_loop_shape_on_our_modules(dev, oracle):
