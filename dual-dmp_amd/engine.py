@@ -131,7 +131,11 @@ class GcnEngine:
     gradients live in caller-owned flat arenas laid out by :class:`ArenaLayout`."""
 
     def __init__(self, graph: ops.Graph, widths: List[int], kind: int, x0: torch.Tensor,
-                 x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None):
+                 x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None,
+                 perm: Optional[torch.Tensor] = None):
+        """``perm`` (int64 [n_rows], new -> old): the engine works on nodes relabelled for gather locality
+        (``graph`` and ``x0``/``x_pos`` must already be in the NEW numbering); :meth:`forward` returns and
+        :meth:`backward` accepts rows in the caller's ORIGINAL numbering."""
         self.g = graph
         self.kind = kind
         self.layout = ArenaLayout(widths)
@@ -165,6 +169,12 @@ class GcnEngine:
         self.num_batches_tracked = torch.zeros(12, dtype=torch.int64, device=dev)
         self.out = torch.empty((self.n_rows, 3), dtype=torch.float32, device=dev)
         self._p1_ready = False
+        self.perm = self.inv = None
+        if perm is not None:
+            self.perm = perm.to(dev)
+            self.inv = torch.empty_like(self.perm)
+            self.inv[self.perm] = torch.arange(self.n_rows, device=dev)
+            self.out_orig = torch.empty_like(self.out)
 
     def _work(self, i, c):
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
@@ -201,6 +211,9 @@ class GcnEngine:
         ops.head_fwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
                      L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, self.x_pos,
                      self.out, n_rows=n)
+        if self.inv is not None:
+            torch.index_select(self.out, 0, self.inv, out=self.out_orig)
+            return self.out_orig
         return self.out
 
     # ------------------------------------------------------------------ backward
@@ -208,6 +221,8 @@ class GcnEngine:
         """Overwrites ``grads`` (same layout as ``params``) with d loss / d params for the last forward."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         dZ = self._work(1, 32)
+        if self.perm is not None:
+            dout = dout.index_select(0, self.perm)
         ops.head_bwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
                      L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, dout.contiguous(), dZ,
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),

@@ -55,9 +55,13 @@ class _FusedNet(nn.Module):
     _widths = None
     _kind = 0
 
-    def __init__(self, device, comm=None):
+    def __init__(self, device, comm=None, reorder="morton"):
+        """``reorder``: node numbering used INSIDE the engine ("morton" = Morton order of the node coordinates --
+        smoothed vertex positions / noisy face centroids --, "bfs" = breadth-first order of the graph, None =
+        keep the caller's).  Results are returned in the caller's numbering either way."""
         super().__init__()
         self.device = torch.device(device)
+        self.reorder = reorder
         self.layout = ArenaLayout(self._widths)
         self.arena = nn.Parameter(torch.zeros(self.layout.total, dtype=torch.float32, device=self.device))
         self.layout.init_(self.arena.data)
@@ -108,12 +112,20 @@ class _FusedNet(nn.Module):
                 and key[2] == (x0._version, edge_index._version))
         if not same:
             dev = self.device
-            graph = getattr(data, "_ddmp_graph_%d" % self._kind, None)
-            if graph is None:
-                graph = ops.graph_for(edge_index.to(dev), x0.shape[0])
-            self._engine = GcnEngine(graph, self._widths, self._kind, x0.detach().to(dev),
-                                     None if x_pos is None else x_pos.to(dev), comm=self.comm,
-                                     n_total=getattr(data, "_ddmp_n_total_%d" % self._kind, None))
+            n = x0.shape[0]
+            perm = self._node_order(x0, x_pos, edge_index, n)
+            if perm is None:
+                graph = ops.graph_for(edge_index.to(dev), n)
+                x0d, xpd = x0.detach().to(dev), None if x_pos is None else x_pos.to(dev)
+            else:
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(n)
+                ei = inv[edge_index.detach().cpu()]
+                self._relabelled = ei.to(dev)                    # keep alive: the graph cache holds a weak ref
+                graph = ops.graph_for(self._relabelled, n)
+                x0d = x0.detach().cpu()[perm].to(dev)
+                xpd = None if x_pos is None else x_pos.detach().cpu()[perm].to(dev)
+            self._engine = GcnEngine(graph, self._widths, self._kind, x0d, xpd, comm=self.comm, perm=perm)
             self._engine_key = (weakref.ref(x0), weakref.ref(edge_index), (x0._version, edge_index._version))
             pend = getattr(self, "_pending_running", None)
             if pend:
@@ -123,6 +135,22 @@ class _FusedNet(nn.Module):
                         if k in pend:
                             self._engine.running[l][j].copy_(pend[k].to(dev))
         return self._engine
+
+    def _coords(self, x0, x_pos):
+        raise NotImplementedError
+
+    def _node_order(self, x0, x_pos, edge_index, n):
+        """new -> old permutation (CPU int64) or None."""
+        if self.reorder is None or self.comm is not None:
+            return None
+        import numpy as np
+        if self.reorder == "morton":
+            from .dist import morton_order
+            return torch.from_numpy(morton_order(self._coords(x0, x_pos).detach().cpu().double().numpy()).astype(np.int64))
+        if self.reorder == "bfs":
+            rowptr, col, _ = ops.csr_build_host(edge_index.detach().cpu().numpy(), n)
+            return torch.from_numpy(ops.bfs_order_host(rowptr, col).astype(np.int64))
+        raise ValueError("reorder must be 'morton', 'bfs' or None")
 
     def forward(self, data):
         self._get_engine(data)
@@ -147,6 +175,9 @@ class PosNetFused(_FusedNet):
     def _inputs(self, data):
         return data.z1, data.x_pos, data.edge_index
 
+    def _coords(self, x0, x_pos):
+        return x_pos                                  # smoothed vertex positions
+
 
 class NormalNetFused(_FusedNet):
     """util/networks.py:69-130."""
@@ -155,6 +186,9 @@ class NormalNetFused(_FusedNet):
 
     def _inputs(self, data):
         return data.z2, None, data.face_index
+
+    def _coords(self, x0, x_pos):
+        return x0[:, :3]                              # z2 = [fc, fn, fa]: face centroids of the noisy mesh
 
 
 # -------------------------------------------------------------------------------- operator-level form

@@ -146,6 +146,18 @@ def permute_vertices(vs, faces, seed=0):
     return vs[perm], inv[faces]
 
 
+def morton_relabel(vs, faces):
+    """Relabel vertices by the Morton order of their positions and faces by the Morton order of their
+    centroids: consecutive ids form compact 2-D patches of the surface (gather locality)."""
+    from .dist import morton_order
+    vo = morton_order(vs)                       # new id -> old id
+    inv = np.empty_like(vo)
+    inv[vo] = np.arange(len(vo))
+    vs2, f2 = vs[vo], inv[faces]
+    fo = morton_order(vs2[f2].mean(1))
+    return vs2, f2[fo]
+
+
 def permute_faces(faces, seed=0):
     rng = np.random.default_rng(seed)
     return faces[rng.permutation(len(faces))]

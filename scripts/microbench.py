@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks at bench scale (HIP-event timing); also the target of rocprofv3 --pmc runs.
+usage: microbench.py [gemm|spmm|bn|all] [--rows N] [--iters K]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dual_dmp_amd import ops, synth
+from dual_dmp_amd.mesh import Mesh
+
+ap = argparse.ArgumentParser()
+ap.add_argument("what", nargs="?", default="all")
+ap.add_argument("--rows", type=int, default=1000000)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--order", default="native")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+n = a.rows
+
+
+def timeit(fn, iters=a.iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3     # us
+
+
+if a.what in ("gemm", "all"):
+    for K, M in ((512, 512), (256, 256), (256, 512), (512, 256), (128, 256)):
+        A = torch.randn(n, K, device=dev); W = torch.randn(M, K, device=dev) / K ** 0.5
+        G = torch.randn(n, M, device=dev)
+        sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev)
+        Y = torch.empty(n, M, device=dev); X = torch.empty(n, K, device=dev); dW = torch.empty(M, K, device=dev)
+        fl = 2.0 * n * K * M
+        for name, fn in (("nt", lambda: ops.gemm_nt(A, W, out=Y)), ("nt+pro", lambda: ops.gemm_nt(A, W, out=Y, pro=(sc, sh))),
+                         ("nn", lambda: ops.gemm_nn(G, W, out=X)), ("tn", lambda: ops.gemm_tn(G, A, out=dW)),
+                         ("tn+pro", lambda: ops.gemm_tn(G, A, out=dW, pro=(sc, sh)))):
+            us = timeit(fn)
+            print("gemm_%-7s K=%3d M=%3d  %8.0f us  %6.1f TF-eq" % (name, K, M, us, fl / us / 1e6))
+
+if a.what in ("spmm", "all"):
+    nu = int(round((n / 2.0) ** 0.5)) if a.what == "spmm_v" else None
+    # face graph of a torus with n faces (deg 3+1) and vertex graph with n/2 verts (deg 6+1)
+    nv_ = int(round((n / 4.0) ** 0.5)); nu_ = n // (2 * nv_)
+    v, f = synth.torus(nu_, nv_)
+    if a.order == "random":
+        v, f = synth.permute_vertices(v, f, 0); f = synth.permute_faces(f, 0)
+    elif a.order == "morton":
+        v, f = synth.morton_relabel(v, f)
+    m = Mesh(vs=v, faces=f)
+    e = torch.tensor(m.edges.T, dtype=torch.long); ei = torch.cat([e, e[[1, 0]]], 1).to(dev)
+    fi = torch.from_numpy(m.f_edges).to(dev)
+    for gname, idx, nn_ in (("face", fi, len(f)), ("vert", ei, len(v))):
+        g = ops.graph_for(idx, nn_)
+        for C in (512, 256, 128, 64, 32):
+            X = torch.randn(nn_, C, device=dev); Y = torch.empty(nn_, C, device=dev)
+            us = timeit(lambda: ops.spmm(g, X, out=Y))
+            alg = 2.0 * nn_ * C * 4 + 4.0 * g.nnz + 8.0 * nn_
+            print("spmm %s N=%d C=%3d  %8.0f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)  gather-logical %.1f GB/s" % (
+                gname, nn_, C, us, alg / us / 1e3, alg / us / 1e3 / 80.0, (g.nnz * C * 4.0 + nn_ * C * 4.0) / us / 1e3))
+
+if a.what in ("bn", "all"):
+    for C in (512, 256):
+        Y = torch.randn(n, C, device=dev); dZ = torch.randn(n, C, device=dev); dY = torch.empty(n, C, device=dev)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        bn4 = torch.rand(4, C, device=dev) + 0.5; c10 = torch.rand(2, C, device=dev)
+        for name, fn, by in (("stats", lambda: ops.bn_stats(Y, sums=sums), 4.0), ("bwd_reduce", lambda: ops.bn_bwd_reduce(dZ, Y, bn4, sums2=sums), 8.0),
+                             ("bwd_apply", lambda: ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, sums), 12.0)):
+            us = timeit(fn)
+            print("bn_%-10s C=%3d %8.0f us  %7.1f GB/s" % (name, C, us, by * n * C / us / 1e3))
