@@ -32,7 +32,8 @@ constexpr int kCu = 256;
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // LeakyReLU with the slope as a runtime value (reference: nn.LeakyReLU() = 0.01)
-__device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : slope * x; }
+// for 0 <= slope <= 1 (the reference: 0.01) LeakyReLU(x) == max(x, slope*x): one mul + one max, no compare/select
+__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, slope * x); }
 __device__ __forceinline__ float lrelu_grad(float x, float slope) { return x > 0.f ? 1.f : slope; }
 
 __device__ __forceinline__ float4 f4_affine_lrelu(float4 v, float4 a, float4 b, float slope) {

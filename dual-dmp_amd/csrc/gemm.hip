@@ -358,10 +358,31 @@ extern "C" int ddmp_get_gemm_mode(void) { return gemm_mode(); }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+extern "C" size_t ddmp_gemm_rows_workspace_bytes(int K, int M) {
+    if (K <= 0 || M <= 0) return 0;
+    return ((size_t)3 * K * M * 2 + 255) / 256 * 256;          // three bf16 planes of W
+}
+
+// bf16 modes with a workspace: W is split ONCE here instead of by every row-tile workgroup
+static bool presplit_w(const float* W, int64_t ldw, int M, int K, int transpose, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+    const int mode = gemm_mode();
+    const int RK = transpose ? M : K;                           // reduction length of the consumer
+    if (mode == 0 || !ws || ws_bytes < ddmp_gemm_rows_workspace_bytes(K, M) || RK % 8 != 0 ||
+        (reinterpret_cast<uintptr_t>(ws) & 15))
+        return false;
+    const int grid = (int)std::min<int64_t>(cdiv((int64_t)M * K, 256), 1024);
+    if (mode == 6)
+        hipLaunchKernelGGL((split_w_kernel<3>), dim3(grid), dim3(256), 0, st, W, ldw, M, K, transpose, (__bf16*)ws);
+    else
+        hipLaunchKernelGGL((split_w_kernel<2>), dim3(grid), dim3(256), 0, st, W, ldw, M, K, transpose, (__bf16*)ws);
+    return hipGetLastError() == hipSuccess;
+}
+
 extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y,
                                 int64_t ldy, int64_t n_rows, int K, int M, const float* bias,
                                 const float* pro_scale, const float* pro_shift, float slope,
-                                ddmp_stream stream) {
+                                void* workspace, size_t workspace_bytes, ddmp_stream stream) {
     ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
     ARG_TRY(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldy >= M);
     ARG_TRY(aligned16(A) && aligned16(W));
@@ -372,21 +393,33 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int TN = M > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+    const bool pre = !(pro_scale && K > 512) && presplit_w(W, ldw, M, K, 0, workspace, workspace_bytes, st);
+    const float* Bop = pre ? (const float*)workspace : W;
 #define DDMP_LAUNCH_NT(KERNEL_, PRO_)                                                                    \
-    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, W, ldw, Y, ldy, (int)n_rows, K, M, bias, \
+    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, Bop, ldw, Y, ldy, (int)n_rows, K, M, bias, \
                        pro_scale, pro_shift, slope, n_row_tiles, n_col_tiles)
+#define DDMP_NT_PICK(TN_, NTERM_, PRO_)                                                                   \
+    do {                                                                                                  \
+        if (pre && kt_) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, NTERM_, false, PRO_, true, true>), PRO_);   \
+        else if (pre) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, NTERM_, false, PRO_, false, true>), PRO_);    \
+        else if (kt_) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, NTERM_, false, PRO_, true, false>), PRO_);    \
+        else DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, NTERM_, false, PRO_, false, false>), PRO_);            \
+    } while (0)
 #define DDMP_NT_BY_MODE(TN_, PRO_)                                                          \
     do {                                                                                    \
-        const int mode_ = gemm_mode();                                                      \
-        if (mode_ == 6) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, 3, false, PRO_>), PRO_); \
-        else if (mode_ == 3) DDMP_LAUNCH_NT((gemm_rows_bf16_kernel<TN_, 2, false, PRO_>), PRO_); \
-        else DDMP_LAUNCH_NT((gemm_rows_kernel<TN_, false, PRO_>), PRO_);                    \
+        const int mode_ = (PRO_ && K > 512) ? 0 : gemm_mode();                              \
+        const bool kt_ = (K % 16) != 0;                                                     \
+        if (mode_ == 6) DDMP_NT_PICK(TN_, 3, PRO_);                                         \
+        else if (mode_ == 3) DDMP_NT_PICK(TN_, 2, PRO_);                                    \
+        else hipLaunchKernelGGL((gemm_rows_kernel<TN_, false, PRO_>), grid, block, 0, st, A, lda, W, ldw, Y, ldy,  \
+                                (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, n_row_tiles, n_col_tiles); \
     } while (0)
     if (TN == 2) {
         if (pro_scale) DDMP_NT_BY_MODE(2, true); else DDMP_NT_BY_MODE(2, false);
     } else {
         if (pro_scale) DDMP_NT_BY_MODE(1, true); else DDMP_NT_BY_MODE(1, false);
     }
+#undef DDMP_NT_PICK
 #undef DDMP_NT_BY_MODE
 #undef DDMP_LAUNCH_NT
     LAUNCH_TRY();
@@ -394,7 +427,8 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 }
 
 extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y,
-                                int64_t ldy, int64_t n_rows, int M, int K, ddmp_stream stream) {
+                                int64_t ldy, int64_t n_rows, int M, int K, void* workspace,
+                                size_t workspace_bytes, ddmp_stream stream) {
     // Y[n,K] = A[n,M] . W[M,K] : reduction over M, output width K
     ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ldy >= K);
@@ -404,19 +438,43 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     const int TN = K > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(K, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+    // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
+    // in its row-major (NT) form on the planes
+    const bool pre = presplit_w(W, ldw, M, K, 1, workspace, workspace_bytes, st);
 #define DDMP_LAUNCH_NN(KERNEL_)                                                                        \
     hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, W, ldw, Y, ldy, (int)n_rows, M, K, nullptr, \
                        nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles)
+#define DDMP_LAUNCH_NNP(KERNEL_)                                                                       \
+    hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, (const float*)workspace, (int64_t)M, Y, ldy, \
+                       (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, n_row_tiles, n_col_tiles)
     const int mode = gemm_mode();
-    if (TN == 2) {
-        if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 3, true, false>));
-        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 2, true, false>));
+    const bool kt = (M % 16) != 0;                 // reduction dimension of the NN form is M
+    if (pre) {
+        if (TN == 2) {
+            if (mode == 6 && kt) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<2, 3, false, false, true, true>));
+            else if (mode == 6) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<2, 3, false, false, false, true>));
+            else if (kt) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<2, 2, false, false, true, true>));
+            else DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<2, 2, false, false, false, true>));
+        } else {
+            if (mode == 6 && kt) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<1, 3, false, false, true, true>));
+            else if (mode == 6) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<1, 3, false, false, false, true>));
+            else if (kt) DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<1, 2, false, false, true, true>));
+            else DDMP_LAUNCH_NNP((gemm_rows_bf16_kernel<1, 2, false, false, false, true>));
+        }
+    } else if (TN == 2) {
+        if (mode == 6 && kt) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 3, true, false, true, false>));
+        else if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 3, true, false, false, false>));
+        else if (mode == 3 && kt) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 2, true, false, true, false>));
+        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<2, 2, true, false, false, false>));
         else DDMP_LAUNCH_NN((gemm_rows_kernel<2, true, false>));
     } else {
-        if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 3, true, false>));
-        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 2, true, false>));
+        if (mode == 6 && kt) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 3, true, false, true, false>));
+        else if (mode == 6) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 3, true, false, false, false>));
+        else if (mode == 3 && kt) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 2, true, false, true, false>));
+        else if (mode == 3) DDMP_LAUNCH_NN((gemm_rows_bf16_kernel<1, 2, true, false, false, false>));
         else DDMP_LAUNCH_NN((gemm_rows_kernel<1, true, false>));
     }
+#undef DDMP_LAUNCH_NNP
 #undef DDMP_LAUNCH_NN
     LAUNCH_TRY();
     return DDMP_OK;

@@ -7,6 +7,7 @@ No wrapper has a CPU path: a non-CUDA tensor raises.
 from __future__ import annotations
 
 import ctypes
+import threading
 import weakref
 
 import numpy as np
@@ -96,13 +97,14 @@ def _mat(t, name="matrix"):
 
 
 class Workspace:
-    """Grow-only scratch buffer (one per device) for split-K partials and column reductions."""
+    """Grow-only scratch buffer for split-K partials, pre-split weights and column reductions: one per
+    (device, stream, host thread) -- logical ranks emulated as threads on one stream must not share it."""
 
     _bufs = {}
 
     @classmethod
     def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+        key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream, threading.get_ident())
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -223,9 +225,11 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
         out = torch.empty((n, M), dtype=torch.float32, device=a.device)
     out, ldy = _mat(out, "out")
     ps, psh = (None, None) if pro is None else pro
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
     with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = _lib.lib().ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh),
-                                         slope, _stream())
+        st = L.ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh),
+                                slope, _p(ws), ws.numel(), _stream())
     check(st, "ddmp_gemm_nt_f32")
     return out
 
@@ -241,8 +245,10 @@ def gemm_nn(a, w, out=None, n_rows=None):
     if out is None:
         out = torch.empty((n, K), dtype=torch.float32, device=a.device)
     out, ldy = _mat(out, "out")
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
     with _timed("gemm_nn", (M, K), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = _lib.lib().ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _stream())
+        st = L.ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _p(ws), ws.numel(), _stream())
     check(st, "ddmp_gemm_nn_f32")
     return out
 

@@ -85,11 +85,14 @@ int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, in
  *   tn : dW[M,K] = G[n,M]^T . f(Z[n,K])                  wgrad, split over rows; needs workspace
  * f as in ddmp_spmm_f32 (per column of A resp. Z).  K, lda, ldz must be multiples of 4.
  */
+size_t ddmp_gemm_rows_workspace_bytes(int K, int M);   /* optional scratch of nt / nn: W pre-split into bf16 planes */
 int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
                      int64_t n_rows, int K, int M, const float* bias,
-                     const float* pro_scale, const float* pro_shift, float slope, ddmp_stream stream);
+                     const float* pro_scale, const float* pro_shift, float slope,
+                     void* workspace /*nullable*/, size_t workspace_bytes, ddmp_stream stream);
 int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
-                     int64_t n_rows, int M, int K, ddmp_stream stream);
+                     int64_t n_rows, int M, int K, void* workspace /*nullable*/, size_t workspace_bytes,
+                     ddmp_stream stream);
 size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
 /* GEMM arithmetic: 6 = bf16x6 split MFMA (default: every f32 operand is split into three bf16 terms, six
  * bf16 MFMA products accumulated in f32 -- f32-class accuracy at 2.67x the f32-MFMA rate), 3 = bf16x3

@@ -18,7 +18,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.status_string(0) == "ok" and _lib.status_string(-4) == "workspace too small"
     # argument validation happens before any device work
     assert lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None) == -1
-    assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None) == -1
+    assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, 0, None) == -1
     assert lib.ddmp_gemm_tn_workspace_bytes(1000000, 512, 512) > 0
 
 
