@@ -32,6 +32,7 @@ import torch         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
 
 def load_oracle():
@@ -116,17 +117,46 @@ def family_table(summary, steps):
     return fam
 
 
+def pmc_traffic(name):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate --pmc passes).
+    bench.py cannot run the profiler itself; None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tot_b = tot_n = 0.0
+    for k in d.get("per_kernel", []):
+        kn = k["kernel"]
+        fam = ("spmm" if "spmm" in kn else "gemm_tn" if "gemm_tn" in kn else "gemm_rows" if "gemm_rows" in kn else kn)
+        want = {"spmm": "spmm", "gemm_tn": "gemm_tn", "gemm_nt": "gemm_rows", "gemm_nn": "gemm_rows"}.get(name, name)
+        if fam == want:
+            tot_b += (k["hbm_read_GB"] + k["hbm_write_GB"]) * 1e9
+            tot_n += k["launches"]
+    return {"bytes_per_launch": round(tot_b / tot_n), "source": os.path.basename(files[-1])} if tot_n else None
+
+
 def roofline_obj(name, f):
     ms = f["ms"]
     if name.startswith("gemm"):
-        ach = f["flops"] / (ms * 1e-3) / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": None,
-                "ms_per_step": round(ms, 3), "launches_per_step": f["calls"]}
+        from dual_dmp_amd import ops
+        mode = ops.get_gemm_mode()
+        f32_eq = f["flops"] / (ms * 1e-3) / 1e12          # algorithmic (f32) FLOP/s
+        if mode == 0:
+            ach, peak, what = f32_eq, MFMA_F32_PEAK_TF, "f32-input MFMA"
+        else:
+            ach, peak, what = f32_eq * mode, MFMA_BF16_PEAK_TF, "bf16x%d split MFMA: %d bf16 MFMA products per f32 product" % (mode, mode)
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": pmc_traffic(name),
+                "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
+                "note": "%s; achieved counts the MFMA flops actually issued; algorithmic f32-equivalent rate = %.1f TFLOP/s "
+                        "(= %.2f of the 157.3 TF f32-input-MFMA peak)" % (what, f32_eq, f32_eq / MFMA_F32_PEAK_TF)}
     ach = f["bytes"] / (ms * 1e-3) / 1e9
     return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "ms_per_step": round(ms, 3), "launches_per_step": f["calls"]}
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
+            "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
+            "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
 
 
 def main():
@@ -242,6 +272,7 @@ def main():
             "value": round(args.steps / elapsed, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "gemm_arithmetic": {6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA"}[ops.get_gemm_mode()],
             "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, float32, k=(3,4,4,4,1), "
                                    "bnfloop=%d, %s numbering (BASELINE.json configs[2])" % (F, V, args.bnfloop, args.order),
                        "faces": F, "verts": V, "parallelism": "1 GPU" if world == 1 else "%d-way face/vertex partition + 1-hop halo" % world,
