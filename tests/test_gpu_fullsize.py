@@ -1,0 +1,145 @@
+"""Size-independent properties at BASELINE.json's full size (synthetic 1,000,000-face / 500,000-vertex mesh),
+where the CPU oracle would take minutes per iteration:
+
+  * A_hat has the eigenpair (1, D^1/2 1): spmm(sqrt(deg)) == sqrt(deg)          (exact structure of gcn_norm)
+  * linearity and self-adjointness of the aggregation (A_hat symmetric)
+  * GEMM with W = I reproduces A bit-exactly (the bf16x6 split sums back to the f32 value), wgrad of all-ones
+    rows equals the float64 column sums
+  * BatchNorm statistics: normalised output has column mean 0 / variance 1
+  * one real training iteration is invariant under the engine's internal node relabelling and under a 2-way
+    partition with halo exchange (threaded logical ranks on the one GPU)
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FACES = 1000000
+
+
+@pytest.fixture(scope="module")
+def big(request):
+    assert torch.cuda.is_available()
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    v, f = synth.torus(1000, 500)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    assert len(noisy.faces) == FACES and len(noisy.vs) == FACES // 2
+    return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("which", ["vertex", "face"])
+def test_aggregation_invariants_at_1m(big, which):
+    from dual_dmp_amd import ops
+    dev = torch.device("cuda:0")
+    gt, noisy, smooth, data = big
+    idx, n = (data.edge_index, len(noisy.vs)) if which == "vertex" else (data.face_index, len(noisy.faces))
+    idx = idx.to(dev)
+    g = ops.graph_for(idx, n)
+    deg = torch.bincount(idx[1], minlength=n).to(torch.float32) + 1.0
+    for C in (512, 32):
+        x = deg.sqrt()[:, None].expand(n, C).contiguous()
+        y = ops.spmm(g, x)
+        assert float((y - x).abs().max()) < 2e-6 * float(x.max()), (which, C)       # eigenvector, eigenvalue 1
+        torch.manual_seed(C)
+        a, b = torch.randn(n, C, device=dev), torch.randn(n, C, device=dev)
+        ya, yb = ops.spmm(g, a), ops.spmm(g, b)
+        assert rel(ops.spmm(g, 2.0 * a + b), 2.0 * ya + yb) < 1e-6                   # linearity
+        lhs = float((ya.double() * b.double()).sum())
+        rhs = float((a.double() * yb.double()).sum())
+        assert abs(lhs - rhs) <= 1e-6 * (abs(lhs) + float(ya.double().norm() * b.double().norm()))  # <Aa,b> = <a,Ab>
+
+
+def test_gemm_identities_at_1m():
+    from dual_dmp_amd import ops
+    dev = torch.device("cuda:0")
+    n, K = FACES, 256
+    torch.manual_seed(0)
+    a = torch.randn(n, K, device=dev)
+    eye = torch.eye(K, device=dev)
+    assert torch.equal(ops.gemm_nt(a, eye), a)                                      # exact in bf16x6 and f32 modes
+    assert torch.equal(ops.gemm_nn(a, eye), a)
+    ones = torch.ones(n, 4, device=dev)
+    dw = ops.gemm_tn(ones, a)                                                        # [4, K] = column sums
+    cs = ops.colsum(a)
+    assert rel(dw[0], cs) < 1e-6 and torch.equal(dw[0], dw[3])
+    # tall-skinny associativity against float64 on a row sample
+    w = torch.randn(512, K, device=dev) / 16
+    y = ops.gemm_nt(a, w)
+    rows = torch.randint(0, n, (2048,), device=dev)
+    assert rel(y[rows], a[rows].double() @ w.double().t()) < 2e-6
+
+
+def test_batchnorm_normalises_at_1m():
+    from dual_dmp_amd import ops
+    dev = torch.device("cuda:0")
+    n, C = FACES, 256
+    torch.manual_seed(1)
+    y = torch.randn(n, C, device=dev) * 3 + 7
+    sums = ops.bn_stats(y)
+    bn4 = torch.empty(4, C, device=dev)
+    ops.bn_prepare(sums, n, torch.ones(C, device=dev), torch.zeros(C, device=dev), bn4)
+    z = ops.bn_lrelu_apply(y, bn4[0], bn4[1], slope=1.0)                            # slope 1: LeakyReLU = identity
+    assert float(z.double().mean(0).abs().max()) < 1e-5
+    assert float((z.double().var(0, unbiased=False) - 1).abs().max()) < 1e-4
+
+
+def test_training_iteration_invariances_at_1m(big):
+    """Same first iteration (a) with and without the internal Morton relabelling, (b) on 2 logical ranks with
+    halo exchange; also: finite, decreasing loss over three iterations."""
+    from dual_dmp_amd import dist as D
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    dev = torch.device("cuda:0")
+    gt, noisy, smooth, data = big
+
+    def run(reorder, steps):
+        torch.manual_seed(0)
+        posnet, normnet = PosNet(dev, reorder=reorder), NormalNet(dev, reorder=reorder)
+        tr = FusedTrainer(posnet, normnet, data, noisy)
+        out = [(tr.step().item(), tr.pos.clone(), tr.norm.clone()) for _ in range(steps)]
+        return out
+
+    base = run("morton", 3)
+    losses = [b[0] for b in base]
+    assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
+    plain = run(None, 1)
+    assert abs(plain[0][0] - base[0][0]) <= 1e-6 * abs(base[0][0])
+    assert float((plain[0][1] - base[0][1]).abs().max()) < 5e-5
+    assert float((plain[0][2] - base[0][2]).abs().max()) < 5e-5
+    del plain
+    torch.cuda.empty_cache()
+
+    P = 2
+    nets = []
+    for _ in range(P):
+        torch.manual_seed(0)
+        nets.append((PosNet(dev), NormalNet(dev)))
+    comms = D.ThreadComm.make(P)
+    res, errs = {}, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            tr = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, backend=comms[r], nets=nets[r])
+            res[r] = (tr.step().item(), tr.pos.clone(), tr.peng.n_rows, tr.peng.n_cols)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            comms[r].s.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for r in range(P):
+        loss, pos, n_rows, n_cols = res[r]
+        assert n_rows < n_cols                                                       # a real halo
+        assert abs(loss - base[0][0]) <= 1e-6 * abs(base[0][0]), (loss, base[0][0])
+        assert float((pos - base[0][1]).abs().max()) < 5e-5
+    assert res[0][2] + res[1][2] == len(noisy.vs)
