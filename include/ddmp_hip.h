@@ -208,6 +208,11 @@ int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, 
  */
 int ddmp_face_normals_f32(int64_t F, const float* pos, const int32_t* faces, float* fn /*[F,3]*/,
                           float* fa /*[F] nullable*/, ddmp_stream stream);
+/* vertex update from predicted normals (util/models.py:31-44): `loop` sweeps of
+ * p_v += mean_{f in F(v)} ((c_f - p_v).n_f) n_f, in place; fc_scratch [F,3] */
+int ddmp_vertex_update_f32(int64_t V, int64_t F, float* pos, const float* norm, const int32_t* faces,
+                           const int32_t* vf_ptr, const int32_t* vf_corner, float* fc_scratch, int loop,
+                           ddmp_stream stream);
 size_t ddmp_mad_workspace_bytes(void);
 int ddmp_mad_f64(int64_t F, const float* n1 /*[F,3] f32*/, const double* n2 /*[F,3] f64*/, double* out /*[1]*/,
                  void* workspace, size_t workspace_bytes, ddmp_stream stream);

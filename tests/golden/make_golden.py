@@ -11,8 +11,8 @@ What is captured:
   loss_<name>.npz   values AND autograd gradients of the five training losses
                     (util/loss.py:16,37,55,86,140) for seeded inputs, bnf loop in {1,5},
                     plus mad / angular_difference (util/loss.py:261-277),
-                    Mesh.compute_face_normals on a displaced mesh (util/mesh.py:87-92) and
-                    models.compute_fn (util/models.py:5-10)
+                    Mesh.compute_face_normals on a displaced mesh (util/mesh.py:87-92),
+                    models.compute_fn (util/models.py:5-10) and models.vertex_updating (:31-44)
 
 ``pymeshlab`` is stubbed at import (util/loss.py:4; only used at :279-284).
 ``util/networks.py`` / ``util/datamaker.py`` cannot be imported (torch_geometric absent):
@@ -141,6 +141,10 @@ def main():
         RefMesh.compute_face_normals(m2)
         out.update(cfn_fn=m2.fn, cfn_fa=m2.fa, mad_pos=np.float64(RefLoss.mad(m2.fn, m.fn)))
         out["models_compute_fn"] = RefModels.compute_fn(pos, m.faces).numpy()
+        # post-process of the paper's pipeline (util/models.py:31-44; dead code in main.py:115,139): move vertices so
+        # that the faces agree with the predicted normals
+        for loop in (1, 3):
+            out["vertex_updating_%d" % loop] = RefModels.vertex_updating(pos, nrm, m, loop=loop).numpy()
         np.savez_compressed(os.path.join(HERE, "loss_%s.npz" % name), **out)
         print(name, "V", V, "F", F, "pos_rec", out["pos_rec"], out["pos_rec"].dtype,
               "lap", out["lap"], "norm_rec", out["norm_rec"], "bnf1", out["bnf1"],

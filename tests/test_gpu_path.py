@@ -419,3 +419,18 @@ def test_cli_runs_like_the_reference(dev, tmp_path, monkeypatch, capsys):
     from dual_dmp_amd.mesh import Mesh
     o = Mesh(str(tmp_path / "datasets" / "ball" / "output" / "10_ddmp.obj"))
     assert np.array_equal(o.faces, noisy.faces) and np.allclose(o.vs, tr.pos.cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_vertex_updating_matches_reference_golden(dev, golden_dir, name):
+    """util/models.py:31-44 (the reference's per-vertex Python loop) vs the two-kernel sweep."""
+    from dual_dmp_amd import models
+    gl = np.load(os.path.join(golden_dir, "loss_%s.npz" % name))
+    m = _golden_mesh(golden_dir, name)
+    pos, nrm = torch.from_numpy(gl["pos"]).to(dev), torch.from_numpy(gl["norm"]).to(dev)
+    for loop in (1, 3):
+        out = models.vertex_updating(pos, nrm, m, loop=loop)
+        np.testing.assert_allclose(out.cpu().numpy(), gl["vertex_updating_%d" % loop], rtol=1e-5, atol=2e-6)
+    assert torch.equal(pos.cpu(), torch.from_numpy(gl["pos"]))                   # input untouched (detach().clone())
+    fn = models.compute_fn(pos, m.faces)
+    np.testing.assert_allclose(fn.cpu().numpy(), gl["models_compute_fn"], atol=2e-6)
