@@ -78,7 +78,11 @@ class HaloPlan:
     """Everything rank `rank` needs for one graph: local CSR over [owned | halo], global ids, and the
     all-to-all schedule.  Built identically (deterministically) on every rank from the global CSR."""
 
-    def __init__(self, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, owner: np.ndarray, rank: int, P: int):
+    def __init__(self, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, owner: np.ndarray, rank: int, P: int,
+                 order_key: Optional[np.ndarray] = None):
+        """``order_key`` [n]: owned rows are stored in increasing key (e.g. the Morton rank of the node) so that
+        consecutive local rows are spatial neighbours; the exchange schedule is keyed on GLOBAL ids and is the
+        same on every rank whatever the local order."""
         n = len(rowptr) - 1
         owner = owner.astype(np.int64)
         rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr).astype(np.int64))
@@ -90,7 +94,9 @@ class HaloPlan:
         dest, node = key // n, key % n
         src = owner[node]
         self.rank, self.P = rank, P
-        self.owned = np.flatnonzero(owner == rank).astype(np.int64)            # ascending global ids
+        self.owned = np.flatnonzero(owner == rank).astype(np.int64)            # ascending global ids ...
+        if order_key is not None:                                               # ... or along the locality key
+            self.owned = self.owned[np.argsort(order_key[self.owned], kind="stable")]
         mine = dest == rank
         o = np.lexsort((node[mine], src[mine]))                                 # grouped by source rank, then id
         self.halo = node[mine][o]
@@ -226,8 +232,14 @@ class ShardedData:
         self.vert_owner = vertex_owner_from_faces(n_mesh.faces, face_owner, V)
         ei = dataset.edge_index.cpu().numpy()
         fi = dataset.face_index.cpu().numpy()
-        self.vplan = HaloPlan(*global_csr(ei, V), self.vert_owner, rank, P)
-        self.fplan = HaloPlan(*global_csr(fi, F), self.face_owner, rank, P)
+        # local row order = Morton rank of the node (smoothed vertex positions / noisy face centroids), the same
+        # locality numbering the single-device engine applies
+        vkey = np.empty(V, dtype=np.int64)
+        vkey[morton_order(dataset.x_pos.detach().cpu().double().numpy())] = np.arange(V)
+        fkey = np.empty(F, dtype=np.int64)
+        fkey[morton_order(np.asarray(n_mesh.fc, dtype=np.float64))] = np.arange(F)
+        self.vplan = HaloPlan(*global_csr(ei, V), self.vert_owner, rank, P, order_key=vkey)
+        self.fplan = HaloPlan(*global_csr(fi, F), self.face_owner, rank, P, order_key=fkey)
         self.z1 = dataset.z1.detach().cpu()[torch.from_numpy(self.vplan.local_ids)]
         self.z2 = dataset.z2.detach().cpu()[torch.from_numpy(self.fplan.local_ids)]
         self.x_pos = dataset.x_pos.detach().cpu()[torch.from_numpy(self.vplan.owned)]

@@ -33,7 +33,9 @@ def test_halo_plans_are_consistent(P, kind):
     vo = D.vertex_owner_from_faces(noisy.faces, fo, V)
     for owner, ei, n in ((fo, data.face_index.numpy(), F), (vo, data.edge_index.numpy(), V)):
         rowptr, col, dinv = ops.csr_build_host(ei, n)
-        plans = [D.HaloPlan(rowptr, col, dinv, owner, r, P) for r in range(P)]
+        rng = np.random.default_rng(P)
+        key = rng.permutation(n) if kind == "grid" else None              # any local order must work
+        plans = [D.HaloPlan(rowptr, col, dinv, owner, r, P, order_key=key) for r in range(P)]
         assert sorted(np.concatenate([p.owned for p in plans]).tolist()) == list(range(n))
         for r, p in enumerate(plans):
             # halo == exactly the non-owned neighbours of owned rows
@@ -56,6 +58,8 @@ def test_halo_plans_are_consistent(P, kind):
                 assert q.send_counts[r] == cnt
                 assert np.array_equal(q.owned[q.send_idx[s0:s0 + cnt]], want)
                 off += cnt
+            if key is not None:
+                assert np.all(np.diff(key[p.owned]) > 0)
 
 
 def _reference_run(noisy, smooth, data, steps, stub, oracle):
