@@ -46,11 +46,25 @@ __global__ __launch_bounds__(256) void scale_by_clip_kernel(float* __restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] *= c;
 }
 
+// device-side step counter (hipGraph replay: the launch arguments are frozen, the step count is not):
+// ++counter, coef = { lr / (1 - b1^t), sqrt(1 - b2^t) }
+__global__ void adam_prepare_kernel(int* __restrict__ counter, float lr, float b1, float b2, float* __restrict__ coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = counter[0] + 1;
+    counter[0] = t;
+    coef[0] = (float)((double)lr / (1.0 - pow((double)b1, (double)t)));
+    coef[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float b1, float b2, float eps, float step_size,
                                                    float bc2_sqrt, const double* __restrict__ sumsq,
-                                                   float max_norm) {
+                                                   float max_norm, const float* __restrict__ coef_dev) {
+    if (coef_dev) {
+        step_size = coef_dev[0];
+        bc2_sqrt = coef_dev[1];
+    }
     const float c = clip_coef(sumsq, max_norm);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * c;
@@ -97,7 +111,27 @@ extern "C" int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, 
     const float bc2_sqrt = (float)std::sqrt(bc2);
     const int grid = (int)std::min<int64_t>(cdiv(n, 256), 2048);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
-                       step_size, bc2_sqrt, clip_sumsq, max_norm);
+                       step_size, bc2_sqrt, clip_sumsq, max_norm, (const float*)nullptr);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_adam_prepare(int32_t* step_counter, float lr, float beta1, float beta2, float* coef,
+                                 ddmp_stream stream) {
+    ARG_TRY(step_counter && coef && lr >= 0.f);
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_counter, lr, beta1, beta2, coef);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                                      float beta2, float eps, const float* coef, const double* clip_sumsq,
+                                      float max_norm, ddmp_stream stream) {
+    ARG_TRY(p && g && m && v && n > 0 && coef);
+    ARG_TRY(!clip_sumsq || max_norm > 0.f);
+    const int grid = (int)std::min<int64_t>(cdiv(n, 256), 2048);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
+                       0.f, 1.f, clip_sumsq, max_norm, coef);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -413,3 +413,14 @@ def adam_step_(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, clip_sumsq=No
     st = _lib.lib().ddmp_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), betas[0], betas[1], eps,
                                        int(step), _p(clip_sumsq), float(max_norm), _stream())
     check(st, "ddmp_adam_step_f32")
+
+
+def adam_prepare(counter, lr, coef, betas=(0.9, 0.999)):
+    """device-side: counter += 1; coef = (lr / (1 - b1^t), sqrt(1 - b2^t))  (int32 [1], float32 [2])."""
+    check(_lib.lib().ddmp_adam_prepare(_p(counter), float(lr), betas[0], betas[1], _p(coef), _stream()), "ddmp_adam_prepare")
+
+
+def adam_step_dev_(p, g, m, v, coef, betas=(0.9, 0.999), eps=1e-8, clip_sumsq=None, max_norm=0.0):
+    st = _lib.lib().ddmp_adam_step_dev_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), betas[0], betas[1], eps, _p(coef),
+                                           _p(clip_sumsq), float(max_norm), _stream())
+    check(st, "ddmp_adam_step_dev_f32")

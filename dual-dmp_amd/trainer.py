@@ -20,7 +20,10 @@ from .loss import LossEngine
 
 class FusedTrainer:
     def __init__(self, posnet, normnet, dataset, n_mesh, pos_lr=0.01, norm_lr=0.01, k=(3.0, 4.0, 4.0, 4.0, 1.0),
-                 grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100):
+                 grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100, use_graph=False):
+        """``use_graph``: replay the whole iteration as one hipGraph (captured on the second call, re-captured
+        when the BNF gate opens at ``bnf_start_epoch``).  Worth it for launch-bound small meshes (13k faces:
+        ~560 launches per iteration); the Adam step count then lives on the device."""
         self.posnet, self.normnet = posnet, normnet
         self.dataset = dataset
         dev = posnet.device
@@ -38,16 +41,17 @@ class FusedTrainer:
         self.epoch = 0          # drives the BNF gate (main.py:101)
         self.t = 0              # optimiser step count (Adam bias correction)
         self.lossbuf = None
+        self.use_graph = use_graph
+        self._graphs = {}       # gate -> torch.cuda.CUDAGraph
+        self._warm = False
+        self._t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._coef = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(2)]
 
-    @torch.no_grad()
-    def step(self):
-        self.epoch += 1
-        self.t += 1
+    def _iteration(self, gate, dev_adam):
         pa, na = self.posnet.arena.data, self.normnet.arena.data
         pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
         pos = self.peng.forward(pa, update_running=True)
         norm = self.neng.forward(na, update_running=True)
-        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
         lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
         self.peng.backward(pa, pg, dpos)
         self.neng.backward(na, ng, dnorm)
@@ -55,12 +59,43 @@ class FusedTrainer:
             self.posnet._reduce_grads()
             self.normnet._reduce_grads()
         ops.grad_sumsq(ng, out=self.sumsq)                                  # clip NormalNet only (main.py:108)
-        ops.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
-        ops.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
-                       clip_sumsq=self.sumsq, max_norm=self.grad_crip)
-        self.lossbuf = lossbuf
-        self.pos, self.norm = pos, norm
-        return lossbuf[5]
+        if dev_adam:
+            ops.adam_prepare(self._t_dev, self.pos_lr, self._coef[0], self.betas)
+            self._t_dev -= 1                                                # one counter, two learning rates
+            ops.adam_prepare(self._t_dev, self.norm_lr, self._coef[1], self.betas)
+            ops.adam_step_dev_(pa, pg, self.m[0], self.v[0], self._coef[0], self.betas, self.eps)
+            ops.adam_step_dev_(na, ng, self.m[1], self.v[1], self._coef[1], self.betas, self.eps,
+                               clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        else:
+            ops.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+            ops.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
+                           clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        return lossbuf, pos, norm
+
+    @torch.no_grad()
+    def step(self):
+        self.epoch += 1
+        self.t += 1
+        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
+        if not self.use_graph:
+            self.lossbuf, self.pos, self.norm = self._iteration(gate, dev_adam=False)
+            return self.lossbuf[5]
+        self._t_dev.fill_(self.t - 1)                                       # keeps load_adam_state / eager steps in sync
+        if not self._warm:                                                  # first call: eager (allocates workspaces)
+            self._warm = True
+            self.lossbuf, self.pos, self.norm = self._iteration(gate, dev_adam=True)
+            return self.lossbuf[5]
+        g = self._graphs.get(gate)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self._cap = self._iteration(gate, dev_adam=True)
+            self._graphs[gate] = (g, self._cap)
+            g = self._graphs[gate]
+        graph, (self.lossbuf, self.pos, self.norm) = g
+        graph.replay()
+        return self.lossbuf[5]
 
     # ------------------------------------------------------------------ state injection (parity harness)
     def load_adam_state(self, which: int, exp_avg: dict, exp_avg_sq: dict, t: int):

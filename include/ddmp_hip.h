@@ -201,6 +201,13 @@ int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm,
 int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
+/* graph-replay form: the step count lives on the device.  ddmp_adam_prepare does ++(*step_counter) and writes
+ * coef = { lr / (1 - beta1^t), sqrt(1 - beta2^t) }; ddmp_adam_step_dev_f32 reads coef instead of host values. */
+int ddmp_adam_prepare(int32_t* step_counter, float lr, float beta1, float beta2, float* coef /*[2]*/,
+                      ddmp_stream stream);
+int ddmp_adam_step_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                           float eps, const float* coef /*[2]*/, const double* clip_sumsq /*nullable*/,
+                           float max_norm, ddmp_stream stream);
 
 /* ------------------------------------------------------------------ evaluation block (main.py:117-123)
  * Face normals of predicted positions (util/mesh.py:87-92; float32 like the reference's float32 `new_pos`)

@@ -81,6 +81,7 @@ def _reference_run(noisy, smooth, data, steps, stub, oracle):
     tr.v = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
     tr.sumsq = torch.zeros(1, dtype=torch.float64)
     tr.epoch = tr.t = 0
+    tr.use_graph = False
     out = []
     for _ in range(steps):
         loss = float(tr.step())
