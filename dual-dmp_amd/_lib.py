@@ -15,7 +15,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libddmp_hip.so")
+LIB_PATH = os.environ.get("DDMP_LIB") or os.path.join(CSRC, "libddmp_hip.so")   # DDMP_LIB: diagnostic builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "ddmp_hip.h")
 
 _SCALARS = {

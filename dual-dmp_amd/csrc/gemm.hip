@@ -336,8 +336,69 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
 }
 
 #include "gemm_bf16x.inc"
+#include "gemm_ws.inc"
 
 }  // namespace
+
+static int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = ddmp::kCu;
+    }
+    return n;
+}
+
+// DDMP_GEMM_WS=0 keeps the one-role-per-wave kernel (A/B comparisons)
+static bool ws_enabled() {
+    static int e = -1;
+    if (e < 0) {
+        const char* v = getenv("DDMP_GEMM_WS");
+        e = (v && atoi(v) == 0) ? 0 : 1;
+    }
+    return e == 1;
+}
+
+// persistent wave-specialised kernel: pre-split W planes [MD][KD], reduction length KD % 32 == 0, KD >= 96
+template <bool PRO>
+static void launch_ws(int mode, const float* A, int64_t lda, const float* W, int64_t ldw, int transpose, void* planes,
+                      float* Y, int64_t ldy, int n_rows, int KD, int MD, const float* bias, const float* ps,
+                      const float* psh, float slope, hipStream_t st) {
+    const int n_row_tiles = (int)ddmp::cdiv(n_rows, kBM);
+    const int TN = MD > 64 ? 2 : 1;
+    {
+        const int BN = 64 * TN;
+        const int64_t total = ddmp::cdiv(MD, BN) * BN * (int64_t)KD;
+        const int sgrid = (int)std::min<int64_t>(ddmp::cdiv(total, 256), 1024);
+        if (mode == 6)
+            hipLaunchKernelGGL((split_w_tiled_kernel<3>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, BN, (__bf16*)planes);
+        else
+            hipLaunchKernelGGL((split_w_tiled_kernel<2>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, BN, (__bf16*)planes);
+    }
+    const int n_col_tiles = (int)ddmp::cdiv(MD, 64 * TN);
+    const int total = (int)ddmp::cdiv(n_row_tiles, ddmp::kXcd) * ddmp::kXcd * n_col_tiles;
+    const int cus = device_cus() / ddmp::kXcd * ddmp::kXcd;
+    dim3 grid((unsigned)std::min(total, cus)), block(512);
+    const __bf16* Bp = (const __bf16*)planes;
+#define DDMP_WS(TN_, NT_)                                                                                      \
+    hipLaunchKernelGGL((gemm_rows_ws_kernel<TN_, NT_, PRO>), grid, block, 0, st, A, lda, Bp, Y, ldy, n_rows, KD, \
+                       MD, bias, ps, psh, slope, n_row_tiles, n_col_tiles)
+    if (TN == 2) {
+        if (mode == 6) DDMP_WS(2, 3); else DDMP_WS(2, 2);
+    } else {
+        if (mode == 6) DDMP_WS(1, 3); else DDMP_WS(1, 2);
+    }
+#undef DDMP_WS
+}
+static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
+    return ws_enabled() && KD % 32 == 0 && KD >= 96 && MD % 4 == 0 && MD <= 1024 && ldy % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+           ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD);
+}
 
 // GEMM arithmetic: 6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA
 static int g_gemm_mode = -1;
@@ -360,7 +421,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 extern "C" size_t ddmp_gemm_rows_workspace_bytes(int K, int M) {
     if (K <= 0 || M <= 0) return 0;
-    return ((size_t)3 * K * M * 2 + 255) / 256 * 256;          // three bf16 planes of W
+    const size_t kp = ((size_t)K + 127) / 128 * 128, mp = ((size_t)M + 127) / 128 * 128;
+    return 3 * kp * mp * 2;                                     // three bf16 planes of W, tile-padded
 }
 
 // bf16 modes with a workspace: W is split ONCE here instead of by every row-tile workgroup
@@ -393,6 +455,12 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int TN = M > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+    if (gemm_mode() != 0 && !(pro_scale && K > 512) && ws_ok(K, M, Y, ldy, workspace, workspace_bytes)) {
+        if (pro_scale) launch_ws<true>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, st);
+        else launch_ws<false>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, slope, st);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     const bool pre = !(pro_scale && K > 512) && presplit_w(W, ldw, M, K, 0, workspace, workspace_bytes, st);
     const float* Bop = pre ? (const float*)workspace : W;
 #define DDMP_LAUNCH_NT(KERNEL_, PRO_)                                                                    \
@@ -440,6 +508,11 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
     // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
     // in its row-major (NT) form on the planes
+    if (gemm_mode() != 0 && ws_ok(M, K, Y, ldy, workspace, workspace_bytes)) {
+        launch_ws<false>(gemm_mode(), A, lda, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, st);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     const bool pre = presplit_w(W, ldw, M, K, 1, workspace, workspace_bytes, st);
 #define DDMP_LAUNCH_NN(KERNEL_)                                                                        \
     hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, A, lda, W, ldw, Y, ldy, (int)n_rows, M, K, nullptr, \

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Diagnostic builds of libddmp_hip.so with -D flags on gemm.hip (timing-only ablations; results are invalid).
+#   scripts/build_ablation.sh NAME "-DDDMP_ABLATE=3" [NAME2 "-D..."] ...   ->  build_abl/libddmp_NAME.so
+# Use with DDMP_LIB=$PWD/build_abl/libddmp_NAME.so python scripts/microbench.py gemm
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p build_abl
+make -s -C dual-dmp_amd/csrc
+others=$(ls dual-dmp_amd/csrc/*.o | grep -v '/gemm.o')
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c dual-dmp_amd/csrc/gemm.hip -o build_abl/gemm_$name.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_abl/libddmp_$name.so build_abl/gemm_$name.o $others ) &
+done
+wait
+ls build_abl/*.so
