@@ -168,7 +168,8 @@ def main():
     ap.add_argument("--order", choices=["native", "random"], default="native",
                     help="vertex/face numbering of the synthetic mesh as handed to the engine")
     ap.add_argument("--bnfloop", type=int, default=1)
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the iteration as one hipGraph (single-GPU path)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: PosNet on a second stream beside NormalNet")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the iteration as one hipGraph (single-GPU path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-faces", type=int, default=20000)
     ap.add_argument("--profile-steps", type=int, default=2)
@@ -204,7 +205,7 @@ def main():
     else:
         posnet, normnet = PosNet(dev), NormalNet(dev)
         data.to(dev)
-        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph))
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph), overlap=bool(args.overlap))
         barrier = lambda: None   # noqa: E731
     setup_s = time.perf_counter() - t_setup
 
@@ -246,6 +247,7 @@ def main():
         ops.PROF = ops.Profiler()
         if hasattr(tr, "use_graph"):
             tr.use_graph = False             # per-launch events need the eager path
+            tr.overlap = False
         for _ in range(args.profile_steps):
             tr.step().item()
         summ = ops.PROF.summary()
@@ -279,7 +281,8 @@ def main():
             "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, float32, k=(3,4,4,4,1), "
                                    "bnfloop=%d, %s numbering (BASELINE.json configs[2])" % (F, V, args.bnfloop, args.order),
                        "faces": F, "verts": V, "parallelism": "1 GPU" if world == 1 else "%d-way face/vertex partition + 1-hop halo" % world,
-                       "setup_s": round(setup_s, 1), "hipgraph_replay": bool(getattr(args, "graph", 0)) and world == 1},
+                       "setup_s": round(setup_s, 1), "hipgraph_replay": bool(args.graph) and world == 1 and not force_dist,
+                       "two_streams": bool(args.overlap) and world == 1 and not force_dist},
             "loss": round(float(loss), 6),
             "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
         }

@@ -38,7 +38,7 @@ def get_parser(real: bool):
     if not real:
         p.add_argument("--viewer", action="store_true", default=True)
         p.add_argument("--port", type=int, default=8080)
-    p.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph per iteration")
+    p.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly on one stream (default: one hipGraph per iteration, PosNet and NormalNet on two streams)")
     p.add_argument("--seed", type=int, default=None, help="torch seed for the weight init (the reference is unseeded)")
     return p
 
@@ -66,7 +66,7 @@ def run(argv=None, real: bool = False):
     dataset.to(device)
     tr = FusedTrainer(posnet, normnet, dataset, n_mesh, pos_lr=args.pos_lr, norm_lr=args.norm_lr,
                       k=(args.k1, args.k2, args.k3, args.k4, args.k5), grad_crip=args.grad_crip, bnfloop=args.bnfloop,
-                      use_graph=not args.no_graph)
+                      use_graph=not args.no_graph, overlap=not args.no_graph)
     out_dir = "datasets/" + mesh_name + "/output"
     os.makedirs(out_dir, exist_ok=True)
     ev = None

@@ -20,10 +20,14 @@ from .loss import LossEngine
 
 class FusedTrainer:
     def __init__(self, posnet, normnet, dataset, n_mesh, pos_lr=0.01, norm_lr=0.01, k=(3.0, 4.0, 4.0, 4.0, 1.0),
-                 grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100, use_graph=False):
+                 grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100, use_graph=False,
+                 overlap=False):
         """``use_graph``: replay the whole iteration as one hipGraph (captured on the second call, re-captured
         when the BNF gate opens at ``bnf_start_epoch``).  Worth it for launch-bound small meshes (13k faces:
-        ~560 launches per iteration); the Adam step count then lives on the device."""
+        ~560 launches per iteration); the Adam step count then lives on the device.
+
+        ``overlap``: PosNet runs on a second HIP stream beside NormalNet (forward, then backward + its Adam
+        update); the two nets only meet in the losses.  Same kernels, same results."""
         self.posnet, self.normnet = posnet, normnet
         self.dataset = dataset
         dev = posnet.device
@@ -42,34 +46,69 @@ class FusedTrainer:
         self.t = 0              # optimiser step count (Adam bias correction)
         self.lossbuf = None
         self.use_graph = use_graph
+        self.overlap = overlap and self.peng.comm.world_size == 1
+        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._graphs = {}       # gate -> torch.cuda.CUDAGraph
         self._warm = False
         self._t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self._coef = [torch.zeros(2, dtype=torch.float32, device=dev) for _ in range(2)]
 
+    def _fork(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+
+    def _join(self):
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        torch.cuda.current_stream().wait_event(ev)
+
     def _iteration(self, gate, dev_adam):
         pa, na = self.posnet.arena.data, self.normnet.arena.data
         pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
-        pos = self.peng.forward(pa, update_running=True)
-        norm = self.neng.forward(na, update_running=True)
-        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
-        self.peng.backward(pa, pg, dpos)
-        self.neng.backward(na, ng, dnorm)
-        if self.peng.comm.world_size > 1:
-            self.posnet._reduce_grads()
-            self.normnet._reduce_grads()
-        ops.grad_sumsq(ng, out=self.sumsq)                                  # clip NormalNet only (main.py:108)
         if dev_adam:
             ops.adam_prepare(self._t_dev, self.pos_lr, self._coef[0], self.betas)
             self._t_dev -= 1                                                # one counter, two learning rates
             ops.adam_prepare(self._t_dev, self.norm_lr, self._coef[1], self.betas)
-            ops.adam_step_dev_(pa, pg, self.m[0], self.v[0], self._coef[0], self.betas, self.eps)
+
+        def pos_update():
+            if dev_adam:
+                ops.adam_step_dev_(pa, pg, self.m[0], self.v[0], self._coef[0], self.betas, self.eps)
+            else:
+                ops.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+
+        if self.overlap:
+            self._fork()
+            with torch.cuda.stream(self._side):
+                pos = self.peng.forward(pa, update_running=True)
+            norm = self.neng.forward(na, update_running=True)
+            self._join()
+        else:
+            pos = self.peng.forward(pa, update_running=True)
+            norm = self.neng.forward(na, update_running=True)
+        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
+        if self.overlap:
+            self._fork()
+            with torch.cuda.stream(self._side):
+                self.peng.backward(pa, pg, dpos)
+                pos_update()
+            self.neng.backward(na, ng, dnorm)
+        else:
+            self.peng.backward(pa, pg, dpos)
+            self.neng.backward(na, ng, dnorm)
+            if self.peng.comm.world_size > 1:
+                self.posnet._reduce_grads()
+                self.normnet._reduce_grads()
+            pos_update()
+        ops.grad_sumsq(ng, out=self.sumsq)                                  # clip NormalNet only (main.py:108)
+        if dev_adam:
             ops.adam_step_dev_(na, ng, self.m[1], self.v[1], self._coef[1], self.betas, self.eps,
                                clip_sumsq=self.sumsq, max_norm=self.grad_crip)
         else:
-            ops.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
             ops.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
                            clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        if self.overlap:
+            self._join()
         return lossbuf, pos, norm
 
     @torch.no_grad()

@@ -82,6 +82,7 @@ def _reference_run(noisy, smooth, data, steps, stub, oracle):
     tr.sumsq = torch.zeros(1, dtype=torch.float64)
     tr.epoch = tr.t = 0
     tr.use_graph = False
+    tr.overlap = False
     out = []
     for _ in range(steps):
         loss = float(tr.step())

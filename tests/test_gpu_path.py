@@ -348,26 +348,29 @@ def test_training_free_running_within_reference_noise_floor(dev, oracle, bnfloop
 
 
 def test_graph_replay_is_bit_identical_to_eager(dev):
-    """The hipGraph-replayed iteration (device-side Adam step count, one captured graph per BNF gate value)
-    launches the same kernels on the same buffers: losses, outputs and parameters must match the eager
-    trainer bit for bit, including across the gate flip at bnf_start_epoch."""
+    """The hipGraph-replayed iteration (device-side Adam step count, one captured graph per BNF gate value) and
+    the two-stream iteration (PosNet beside NormalNet) launch the same kernels on the same buffers: losses,
+    outputs and parameters must match the eager trainer bit for bit, including across the gate flip."""
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
     gt, noisy, smooth, data = _case(dev, "grid")
     runs = {}
-    for graph in (False, True):
+    for graph in (False, True, "overlap", "overlap+graph"):
         torch.manual_seed(5)
         posnet, normnet = PosNet(dev), NormalNet(dev)
-        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=4, use_graph=graph)
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=4,
+                          use_graph=graph in (True, "overlap+graph"), overlap=str(graph).startswith("overlap"))
         losses = []
         for _ in range(9):
             losses.append(tr.step().item())
         runs[graph] = (losses, tr.pos.clone(), tr.norm.clone(), posnet.arena.data.clone(), normnet.arena.data.clone(),
                        tr.lossbuf.clone())
-    a, b = runs[False], runs[True]
-    assert a[0] == b[0]
-    for x, y in zip(a[1:], b[1:]):
-        assert torch.equal(x, y)
+    a = runs[False]
+    for key in (True, "overlap", "overlap+graph"):
+        b = runs[key]
+        assert a[0] == b[0], key
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y), key
     assert a[5][3] > 0                                     # the gate did open
 
 
