@@ -337,6 +337,7 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
 
 #include "gemm_bf16x.inc"
 #include "gemm_ws.inc"
+#include "gemm_panel.inc"
 
 }  // namespace
 
@@ -394,6 +395,48 @@ static void launch_ws(int mode, const float* A, int64_t lda, const float* W, int
     }
 #undef DDMP_WS
 }
+// DDMP_GEMM_PANEL=0 disables the row-panel kernel (A/B comparisons)
+static bool panel_enabled() {
+    static int e = -1;
+    if (e < 0) {
+        const char* v = getenv("DDMP_GEMM_PANEL");
+        e = (v && atoi(v) == 0) ? 0 : 1;
+    }
+    return e == 1;
+}
+static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
+    return panel_enabled() && KD % 32 == 0 && KD >= 64 && MD % 4 == 0 && MD > 128 && MD <= 512 && ws &&
+           (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
+           ldy >= MD && Y;
+}
+template <bool PRO>
+static void launch_panel(int mode, const float* A, int64_t lda, const float* W, int64_t ldw, int transpose, void* planes,
+                         float* Y, int64_t ldy, int n_rows, int KD, int MD, const float* bias, const float* ps,
+                         const float* psh, float slope, hipStream_t st) {
+    const int WC = MD > 256 ? 4 : 2, WR = 8 / WC;
+    const int MP = 128 * WC, BMR = 64 * WR;
+    const int n_row_tiles = (int)ddmp::cdiv(n_rows, BMR);
+    {
+        const int64_t total = (int64_t)MP * KD;
+        const int sgrid = (int)std::min<int64_t>(ddmp::cdiv(total, 256), 1024);
+        if (mode == 6)
+            hipLaunchKernelGGL((split_w_panel_kernel<3>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes);
+        else
+            hipLaunchKernelGGL((split_w_panel_kernel<2>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes);
+    }
+    dim3 grid((unsigned)std::min(n_row_tiles, device_cus())), block(512);
+    const __bf16* Bp = (const __bf16*)planes;
+#define DDMP_PANEL(WR_, WC_, NT_)                                                                                \
+    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PRO>), grid, block, 0, st, A, lda, Bp, Y, ldy, n_rows, KD, \
+                       MD, bias, ps, psh, slope, n_row_tiles)
+    if (WC == 4) {
+        if (mode == 6) DDMP_PANEL(2, 4, 3); else DDMP_PANEL(2, 4, 2);
+    } else {
+        if (mode == 6) DDMP_PANEL(4, 2, 3); else DDMP_PANEL(4, 2, 2);
+    }
+#undef DDMP_PANEL
+}
+
 static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
     return ws_enabled() && KD % 32 == 0 && KD >= 96 && MD % 4 == 0 && MD <= 1024 && ldy % 4 == 0 &&
            (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
@@ -455,6 +498,12 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int TN = M > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
+    if (gemm_mode() != 0 && !(pro_scale && K > 512) && panel_ok(K, M, Y, ldy, workspace, workspace_bytes)) {
+        if (pro_scale) launch_panel<true>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, st);
+        else launch_panel<false>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, slope, st);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     if (gemm_mode() != 0 && !(pro_scale && K > 512) && ws_ok(K, M, Y, ldy, workspace, workspace_bytes)) {
         if (pro_scale) launch_ws<true>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, st);
         else launch_ws<false>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, slope, st);
@@ -508,6 +557,11 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
     // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
     // in its row-major (NT) form on the planes
+    if (gemm_mode() != 0 && panel_ok(M, K, Y, ldy, workspace, workspace_bytes)) {
+        launch_panel<false>(gemm_mode(), A, lda, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, st);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     if (gemm_mode() != 0 && ws_ok(M, K, Y, ldy, workspace, workspace_bytes)) {
         launch_ws<false>(gemm_mode(), A, lda, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, st);
         LAUNCH_TRY();
