@@ -313,12 +313,27 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 }
 
 struct TnPlan {
-    int T, n_tiles_m, n_tiles_k, n_splits, rows_per_split;
+    int T, n_tiles_m, n_tiles_k, n_splits, rows_per_split;      // T = 4: 256 x 256 panels (gemm_tn_panel_kernel)
 };
+
+bool tn_panel_enabled();
 
 TnPlan tn_plan(int64_t n_rows, int M, int K) {
     TnPlan p;
     p.T = (M >= 128 && K >= 128) ? 2 : 1;
+    if (M >= 256 && K >= 256 && tn_panel_enabled()) {
+        p.T = 4;
+        p.n_tiles_m = (int)cdiv(M, 256);
+        p.n_tiles_k = (int)cdiv(K, 256);
+        const int tiles = p.n_tiles_m * p.n_tiles_k;
+        // one 512-thread workgroup per CU; at least 1024 rows per split; multiple of 8 splits (XCD mapping)
+        int64_t s = std::min<int64_t>(std::max<int64_t>(1, kCu / tiles), std::max<int64_t>(1, n_rows / 1024));
+        s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
+        int64_t rps = cdiv(cdiv(n_rows, s), 32) * 32;
+        p.rows_per_split = (int)rps;
+        p.n_splits = (int)cdiv(n_rows, rps);
+        return p;
+    }
     const int bt = 64 * p.T;
     p.n_tiles_m = (int)cdiv(M, bt);
     p.n_tiles_k = (int)cdiv(K, bt);
@@ -339,6 +354,13 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
 #include "gemm_ws.inc"
 #include "gemm_panel.inc"
 
+}  // namespace
+
+namespace {
+bool tn_panel_enabled() {                                       // DDMP_GEMM_PANEL=0 / DDMP_GEMM_MODE=0: tiled kernels
+    const char* v = getenv("DDMP_GEMM_PANEL");
+    return !(v && atoi(v) == 0) && ddmp_get_gemm_mode() != 0;
+}
 }  // namespace
 
 static int device_cus() {
@@ -629,6 +651,24 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     float* part = (float*)workspace;
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    if (p.T == 4) {
+        dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
+#define DDMP_LAUNCH_TNP(KERNEL_)                                                                              \
+    hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride, (int)n_rows, \
+                       M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope)
+        const int mode_ = gemm_mode();
+        if (pro_scale) {
+            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true>));
+        } else {
+            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false>));
+        }
+#undef DDMP_LAUNCH_TNP
+        LAUNCH_TRY();
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part,
+                           sstride, p.n_splits, dW, lddw, M, K);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(256);
 #define DDMP_LAUNCH_TN(KERNEL_)                                                                           \
     hipLaunchKernelGGL((KERNEL_), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride, (int)n_rows, \
