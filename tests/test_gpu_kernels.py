@@ -105,7 +105,11 @@ GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6}
 
 
 @pytest.mark.parametrize("n,K,M", [(1000, 32, 64), (777, 512, 512), (130, 8, 32), (513, 256, 128),
-                                   (300, 16, 32), (2000, 64, 32), (129, 128, 256), (50, 32, 3)])
+                                   (300, 16, 32), (2000, 64, 32), (129, 128, 256), (50, 32, 3),
+                                   # row-panel kernels: padded column panels (M < 128*WC), short K, ragged row tiles,
+                                   # and more row tiles than CUs (the persistent loop crosses tile boundaries)
+                                   (1000, 96, 384), (300, 64, 260), (2500, 320, 384), (70001, 64, 256),
+                                   (40000, 256, 512)])
 def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
     from dual_dmp_amd import ops
     tol = GEMM_TOL[gemm_mode]
