@@ -431,10 +431,11 @@ static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const v
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
 }
-template <bool PRO>
-static void launch_panel(int mode, const float* A, int64_t lda, const float* W, int64_t ldw, int transpose, void* planes,
-                         float* Y, int64_t ldy, int n_rows, int KD, int MD, const float* bias, const float* ps,
-                         const float* psh, float slope, hipStream_t st) {
+template <int PM>
+static void launch_panel(int mode, const float* A, int64_t lda, const float* A2, int64_t lda2, const float* W,
+                         int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
+                         const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
+                         float slope, hipStream_t st) {
     const int WC = MD > 256 ? 4 : 2, WR = 8 / WC;
     const int MP = 128 * WC, BMR = 64 * WR;
     const int n_row_tiles = (int)ddmp::cdiv(n_rows, BMR);
@@ -449,8 +450,8 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* W, 
     dim3 grid((unsigned)std::min(n_row_tiles, device_cus())), block(512);
     const __bf16* Bp = (const __bf16*)planes;
 #define DDMP_PANEL(WR_, WC_, NT_)                                                                                \
-    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PRO>), grid, block, 0, st, A, lda, Bp, Y, ldy, n_rows, KD, \
-                       MD, bias, ps, psh, slope, n_row_tiles)
+    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy,   \
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles)
     if (WC == 4) {
         if (mode == 6) DDMP_PANEL(2, 4, 3); else DDMP_PANEL(2, 4, 2);
     } else {
@@ -521,8 +522,8 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
     if (gemm_mode() != 0 && !(pro_scale && K > 512) && panel_ok(K, M, Y, ldy, workspace, workspace_bytes)) {
-        if (pro_scale) launch_panel<true>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, slope, st);
-        else launch_panel<false>(gemm_mode(), A, lda, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, slope, st);
+        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st);
+        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st);
         LAUNCH_TRY();
         return DDMP_OK;
     }
@@ -580,7 +581,7 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
     // in its row-major (NT) form on the planes
     if (gemm_mode() != 0 && panel_ok(M, K, Y, ldy, workspace, workspace_bytes)) {
-        launch_panel<false>(gemm_mode(), A, lda, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, 0.f, st);
+        launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, st);
         LAUNCH_TRY();
         return DDMP_OK;
     }
@@ -654,13 +655,15 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     if (p.T == 4) {
         dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
 #define DDMP_LAUNCH_TNP(KERNEL_)                                                                              \
-    hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride, (int)n_rows, \
-                       M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope)
+    hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, G, ldg, (const float*)nullptr, (int64_t)0, Z, ldz, part, \
+                       (int64_t)K, sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k,       \
+                       p.n_splits, pro_scale, pro_shift, (const float*)nullptr, (const float*)nullptr,           \
+                       (const float*)nullptr, (const float*)nullptr, slope)
         const int mode_ = gemm_mode();
         if (pro_scale) {
-            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true>));
+            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, false>));
         } else {
-            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false>));
+            if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false, false>));
         }
 #undef DDMP_LAUNCH_TNP
         LAUNCH_TRY();
@@ -690,6 +693,67 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     LAUNCH_TRY();
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part,
                        sstride, p.n_splits, dW, lddw, M, K);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+
+// ---- BatchNorm+LeakyReLU backward fused into the operand load of the two GEMMs that consume dY (agg-first layers)
+extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin) {
+    if (gemm_mode() == 0 || !panel_enabled() || !tn_panel_enabled()) return 0;
+    const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin > 128 && cin <= 512;
+    const bool tn = cout >= 256 && cin >= 256 && cout % 4 == 0;
+    return (nn && tn) ? 1 : 0;
+}
+
+extern "C" int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W,
+                                      int64_t ldw, float* out, int64_t ld_out, int64_t n_rows, int M, int K,
+                                      const float* a, const float* b, const float* c1, const float* c0, float slope,
+                                      void* workspace, size_t workspace_bytes, ddmp_stream stream) {
+    // out[n,K] = dY[n,M] . W[M,K],  dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0  (per column of M)
+    ARG_TRY(dZ && Yb && W && out && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
+    ARG_TRY(lddz % 4 == 0 && ldyb % 4 == 0 && ldw % 4 == 0 && lddz >= M && ldyb >= M && ldw >= K && ld_out >= K);
+    ARG_TRY(aligned16(dZ) && aligned16(Yb) && aligned16(W));
+    if (!ddmp_gemm_bnbwd_supported(M, K) || !panel_ok(M, K, out, ld_out, workspace, workspace_bytes)) return DDMP_EINVAL;
+    launch_panel<2>(gemm_mode(), dZ, lddz, Yb, ldyb, W, ldw, 1, workspace, out, ld_out, (int)n_rows, M, K, nullptr, a, b,
+                    c1, c0, slope, (hipStream_t)stream);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* Z,
+                                      int64_t ldz, float* dW, int64_t lddw, int64_t n_rows, int M, int K,
+                                      const float* a, const float* b, const float* c1, const float* c0,
+                                      const float* pro_scale, const float* pro_shift, float slope, void* workspace,
+                                      size_t workspace_bytes, ddmp_stream stream) {
+    // dW[M,K] = dY^T . f(Z),  dY as above (columns of M), f = optional BatchNorm+LeakyReLU prologue on Z (columns of K)
+    ARG_TRY(dZ && Yb && Z && dW && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
+    ARG_TRY(M % 4 == 0 && K % 4 == 0 && lddz >= M && ldyb >= M && ldz >= K && lddw >= K);
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    if (!ddmp_gemm_bnbwd_supported(M, K)) return DDMP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    TnPlan p = tn_plan(n_rows, M, K);
+    if (p.T != 4) return DDMP_EINVAL;
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
+    float* part = (float*)workspace;
+    const int64_t sstride = (int64_t)M * K;
+    const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
+#define DDMP_LAUNCH_TNP(KERNEL_)                                                                                 \
+    hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, dZ, lddz, Yb, ldyb, Z, ldz, part, (int64_t)K, sstride,     \
+                       (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale,       \
+                       pro_shift, a, b, c1, c0, slope)
+    const int mode_ = gemm_mode();
+    if (pro_scale) {
+        if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, true>));
+    } else {
+        if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false, true>));
+    }
+#undef DDMP_LAUNCH_TNP
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part, sstride,
+                       p.n_splits, dW, lddw, M, K);
     LAUNCH_TRY();
     return DDMP_OK;
 }

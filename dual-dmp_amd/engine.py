@@ -150,7 +150,12 @@ class GcnEngine:
         self.x0 = torch.zeros((self.n_cols, L.cin_p[0]), dtype=torch.float32, device=dev)
         self.x0[:, :L.cin[0]] = x0[:self.n_cols].to(torch.float32)
         self.x_pos = None if x_pos is None else x_pos[:self.n_rows].contiguous().to(torch.float32)
-        self.agg_first = [L.cin_p[l] < L.cout[l] for l in range(12)]
+        # aggregate on the narrower side; equal widths aggregate first too: then dY feeds only GEMMs and, where the
+        # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
+        self.agg_first = [L.cin_p[l] <= L.cout[l] for l in range(12)]
+        supported = getattr(ops, "gemm_bnbwd_supported", None)
+        self.fuse_bnbwd = [bool(supported) and l > 0 and self.agg_first[l] and supported(L.cout[l], L.cin_p[l])
+                           for l in range(12)]
         cmax = max(L.cout)
         nc = self.n_cols
 
@@ -239,6 +244,19 @@ class GcnEngine:
             ops.bn_bwd_prepare(self.sums, self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % i),
                                L.view(grads, "bn%d.bias" % i), self.c10[:, :co])
             others = [k for k in range(3) if k != cur]
+            if self.fuse_bnbwd[l]:
+                # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads.
+                # Its column sums (the conv-bias gradient) are exactly zero in exact arithmetic -- BatchNorm's backward
+                # output has zero column mean -- where the reference's autograd leaves float32 summation noise.
+                L.view(grads, "conv%d.bias" % i).zero_()
+                ops.gemm_tn_bnbwd(dZ, Y, self.P[l], self.bn4[l], self.c10[:, :co], out=dW, n_rows=n)
+                dP = self._work(others[0], ci)
+                ops.gemm_nn_bnbwd(dZ, Y, W, self.bn4[l], self.c10[:, :co], out=dP, n_rows=n)
+                comm.halo_exchange(dP, n)
+                dZ = self._work(others[1], ci)
+                ops.spmm(g, dP, out=dZ[:n])
+                cur = others[1]
+                continue
             dY = self._work(others[0], co)
             ops.bn_bwd_apply(dZ, Y, self.bn4[l], self.c10[:, :co], dY, self.sums, n_rows=n)
             ops.f64_to_f32(self.sums[:co], L.view(grads, "conv%d.bias" % i))

@@ -273,6 +273,51 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
     return out
 
 
+def gemm_bnbwd_supported(cout, cin):
+    """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout in the current GEMM mode?"""
+    return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin)))
+
+
+def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
+    """out[n,K] = dY[n,M] @ w[M,K] with dY = BatchNorm+LeakyReLU backward of (dz, yb) computed on the operand load
+    (what bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
+    dz, lddz = _mat(dz, "dz")
+    yb, ldyb = _mat(yb, "yb")
+    w, ldw = _mat(w, "w")
+    n = dz.shape[0] if n_rows is None else n_rows
+    M, K = w.shape
+    if out is None:
+        out = torch.empty((n, K), dtype=torch.float32, device=dz.device)
+    out, ldo = _mat(out, "out")
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
+    with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_nn_bnbwd_f32(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                      _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_gemm_nn_bnbwd_f32")
+    return out
+
+
+def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=None):
+    """out[M,K] = dY^T @ f(z) with dY as in gemm_nn_bnbwd."""
+    dz, lddz = _mat(dz, "dz")
+    yb, ldyb = _mat(yb, "yb")
+    z, ldz = _mat(z, "z")
+    n = dz.shape[0] if n_rows is None else n_rows
+    M, K = yb.shape[1], z.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+    out, ldo = _mat(out, "out")
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_gemm_tn_workspace_bytes(n, M, K), dz.device)
+    ps, psh = (None, None) if pro is None else pro
+    with _timed("gemm_tn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_tn_bnbwd_f32(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                      _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_gemm_tn_bnbwd_f32")
+    return out
+
+
 def _colws(n, C, device):
     need = _lib.lib().ddmp_colreduce_workspace_bytes(n, C)
     if need == 0:

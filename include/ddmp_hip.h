@@ -201,6 +201,22 @@ int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm,
 int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
+/* BatchNorm+LeakyReLU backward fused into the operand load of the GEMMs that consume dY (agg-first layers of the
+ * engine; replaces ddmp_bn_bwd_apply_f32 + ddmp_gemm_nn_f32 + ddmp_gemm_tn_f32 of util/networks.py's autograd chain):
+ *     dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0        (a, b, c1, c0 per column, from ddmp_bn_bwd_prepare_f32)
+ * ddmp_gemm_bnbwd_supported(cout, cin) says whether BOTH fused GEMMs exist for a layer of that shape in the current
+ * GEMM mode; the conv-bias gradient (column sums of dY) is exactly zero in exact arithmetic and is written as 0. */
+int ddmp_gemm_bnbwd_supported(int cout, int cin);
+int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,
+                           float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b,
+                           const float* c1, const float* c0, float slope, void* workspace, size_t workspace_bytes,
+                           ddmp_stream stream);
+int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* Z, int64_t ldz,
+                           float* dW, int64_t lddw, int64_t n_rows, int M, int K, const float* a, const float* b,
+                           const float* c1, const float* c0, const float* pro_scale /*nullable*/,
+                           const float* pro_shift /*nullable*/, float slope, void* workspace, size_t workspace_bytes,
+                           ddmp_stream stream);
+
 /* graph-replay form: the step count lives on the device.  ddmp_adam_prepare does ++(*step_counter) and writes
  * coef = { lr / (1 - beta1^t), sqrt(1 - beta2^t) }; ddmp_adam_step_dev_f32 reads coef instead of host values. */
 int ddmp_adam_prepare(int32_t* step_counter, float lr, float beta1, float beta2, float* coef /*[2]*/,

@@ -130,6 +130,37 @@ def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
         assert relerr(dw, g.double().t() @ f_ref(a.double(), sc.double(), sh.double())) < tol
 
 
+@pytest.mark.parametrize("n,cin,cout", [(777, 256, 512), (3000, 512, 512), (1300, 256, 256), (70001, 256, 256)])
+def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
+    """dgrad / wgrad with the BatchNorm+LeakyReLU backward folded into the operand load == bn_bwd_apply followed by
+    the plain GEMMs (same arithmetic per element, so only the GEMM rounding differs) and == the float64 formula."""
+    from dual_dmp_amd import ops
+    if not ops.gemm_bnbwd_supported(cout, cin):
+        pytest.skip("fused kernels not available in this GEMM mode")
+    torch.manual_seed(n + cin)
+    dz, yb = torch.randn(n, cout), torch.randn(n, cout) * 2 + 0.5
+    w, p = torch.randn(cout, cin) / cout ** 0.5, torch.randn(n, cin)
+    bn4 = torch.stack([torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(cout), torch.rand(cout) + 0.5])
+    c10 = torch.stack([torch.randn(cout) * 0.1, torch.randn(cout) * 0.1])
+    a, b, k1, k0 = bn4[0].double(), bn4[1].double(), c10[0].double(), c10[1].double()
+    z = yb.double() * a + b
+    dy_ref = a * dz.double() * torch.where(z > 0, 1.0, 0.01) + k1 * yb.double() + k0
+    dzg, ybg, wg, pg, bn4g, c10g = (t.to(dev) for t in (dz, yb, w, p, bn4, c10))
+    dx = ops.gemm_nn_bnbwd(dzg, ybg, wg, bn4g, c10g)
+    assert relerr(dx, dy_ref @ w.double()) < 3e-6
+    dw = ops.gemm_tn_bnbwd(dzg, ybg, pg, bn4g, c10g)
+    assert relerr(dw, dy_ref.t() @ p.double()) < 3e-6
+    sc, sh = (torch.rand(cin) + 0.5).to(dev), torch.randn(cin).to(dev)
+    dw = ops.gemm_tn_bnbwd(dzg, ybg, pg, bn4g, c10g, pro=(sc, sh))
+    assert relerr(dw, dy_ref.t() @ f_ref(p.double(), sc.cpu().double(), sh.cpu().double())) < 3e-6
+    # against the unfused composition on the device
+    dy = torch.empty_like(dzg)
+    sums = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    ops.bn_bwd_apply(dzg, ybg, bn4g, c10g, dy, sums)
+    assert relerr(dy, dy_ref) < 1e-6
+    assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
+
+
 def test_gemm_transpose_detecting(dev, gemm_mode):
     """A = I with an asymmetric W: a swapped C-write would show."""
     from dual_dmp_amd import ops
