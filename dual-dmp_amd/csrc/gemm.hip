@@ -435,7 +435,7 @@ template <int PM>
 static void launch_panel(int mode, const float* A, int64_t lda, const float* A2, int64_t lda2, const float* W,
                          int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
                          const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
-                         float slope, hipStream_t st) {
+                         float slope, hipStream_t st, float* stats = nullptr, double* sums = nullptr) {
     const int WC = MD > 256 ? 4 : 2, WR = 8 / WC;
     const int MP = 128 * WC, BMR = 64 * WR;
     const int n_row_tiles = (int)ddmp::cdiv(n_rows, BMR);
@@ -451,13 +451,16 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
     const __bf16* Bp = (const __bf16*)planes;
 #define DDMP_PANEL(WR_, WC_, NT_)                                                                                \
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy,   \
-                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles)
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats)
     if (WC == 4) {
         if (mode == 6) DDMP_PANEL(2, 4, 3); else DDMP_PANEL(2, 4, 2);
     } else {
         if (mode == 6) DDMP_PANEL(4, 2, 3); else DDMP_PANEL(4, 2, 2);
     }
 #undef DDMP_PANEL
+    if (stats && sums)
+        hipLaunchKernelGGL(panel_stats_reduce_kernel, dim3((unsigned)ddmp::cdiv(MD, 32)), dim3(256), 0, st, stats,
+                           n_row_tiles * WR, MP, MD, sums);
 }
 
 static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
@@ -756,4 +759,37 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
                        p.n_splits, dW, lddw, M, K);
     LAUNCH_TRY();
     return DDMP_OK;
+}
+
+
+// ---- forward GEMM that also returns the BatchNorm statistics of its output (column sums of Y and Y^2, float64 [2M]):
+//      fused into the row-panel kernel's epilogue where that kernel runs, otherwise GEMM + ddmp_bn_stats_f32
+extern "C" size_t ddmp_gemm_nt_stats_workspace_bytes(int64_t n_rows, int M) {
+    if (n_rows <= 0 || M <= 0) return 0;
+    const size_t fused = (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(float);
+    return std::max(fused, ddmp_colreduce_workspace_bytes(n_rows, M));
+}
+
+extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
+                                      int64_t n_rows, int K, int M, const float* bias, const float* pro_scale,
+                                      const float* pro_shift, float slope, double* sums2, void* workspace,
+                                      size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                                      ddmp_stream stream) {
+    ARG_TRY(sums2 && stats_ws);
+    if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, M)) return DDMP_EWORKSPACE;
+    const bool fused = A && W && Y && n_rows > 0 && n_rows < INT32_MAX && K > 0 && M > 0 && K % 4 == 0 && lda % 4 == 0 &&
+                       ldw % 4 == 0 && lda >= K && ldw >= K && ldy >= M && aligned16(A) && aligned16(W) &&
+                       (pro_scale == nullptr) == (pro_shift == nullptr) && gemm_mode() != 0 && !(pro_scale && K > 512) &&
+                       panel_ok(K, M, Y, ldy, workspace, workspace_bytes);
+    if (fused) {
+        hipStream_t st = (hipStream_t)stream;
+        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (float*)stats_ws, sums2);
+        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, (float*)stats_ws, sums2);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
+    int rc = ddmp_gemm_nt_f32(A, lda, W, ldw, Y, ldy, n_rows, K, M, bias, pro_scale, pro_shift, slope, workspace,
+                              workspace_bytes, stream);
+    if (rc != DDMP_OK) return rc;
+    return ddmp_bn_stats_f32(Y, ldy, n_rows, M, sums2, stats_ws, stats_ws_bytes, stream);
 }

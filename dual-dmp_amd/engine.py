@@ -200,13 +200,17 @@ class GcnEngine:
                         comm.halo_exchange(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
                     self._p1_ready = True
-                ops.gemm_nt(P, W, out=Y, bias=b, n_rows=n)
+                if hasattr(ops, "gemm_nt_stats"):                # BatchNorm statistics from the GEMM epilogue
+                    ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n)
+                else:
+                    ops.gemm_nt(P, W, out=Y, bias=b, n_rows=n)
+                    ops.bn_stats(Y, sums=self.sums, n_rows=n)
             else:
                 H = self._work(0, L.cout[l])
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n)
                 comm.halo_exchange(H, n)
                 ops.spmm(g, H, out=Y[:n], bias=b)
-            ops.bn_stats(Y, sums=self.sums, n_rows=n)
+                ops.bn_stats(Y, sums=self.sums, n_rows=n)
             comm.all_reduce_sum(self.sums[: 2 * L.cout[l]])
             ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
                            self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)

@@ -234,6 +234,30 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     return out
 
 
+def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
+    """gemm_nt that also fills ``sums`` (float64 [2M]) with the column sums of out and out^2 (= bn_stats(out)):
+    produced in the row-panel kernel's epilogue where that kernel runs, by a separate pass otherwise."""
+    a, lda = _mat(a, "a")
+    w, ldw = _mat(w, "w")
+    n = a.shape[0] if n_rows is None else n_rows
+    K, M = a.shape[1], w.shape[0]
+    if w.shape[1] != K:
+        raise DdmpError("gemm_nt: inner dimensions differ (%d vs %d)" % (K, w.shape[1]))
+    if out is None:
+        out = torch.empty((n, M), dtype=torch.float32, device=a.device)
+    out, ldy = _mat(out, "out")
+    ps, psh = (None, None) if pro is None else pro
+    L = _lib.lib()
+    nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
+    sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, M)
+    ws = Workspace.get(nb + sb, a.device)
+    with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_nt_stats_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
+                                      _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream())
+    check(st, "ddmp_gemm_nt_stats_f32")
+    return out
+
+
 def gemm_nn(a, w, out=None, n_rows=None):
     """out[n,K] = a[n,M] @ w[M,K]."""
     a, lda = _mat(a, "a")

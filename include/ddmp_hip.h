@@ -201,6 +201,17 @@ int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm,
 int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
+/* ddmp_gemm_nt_f32 that also returns the BatchNorm statistics of its output (float64 [2M]: column sums of Y and of
+ * Y^2 over the n_rows rows = what ddmp_bn_stats_f32(Y) returns; GCNConv -> BatchNorm1d, util/networks.py:52-53).  The
+ * row-panel kernel produces them in its epilogue (float32 partials per 64 rows, summed in float64); other shapes run
+ * the GEMM followed by ddmp_bn_stats_f32. */
+size_t ddmp_gemm_nt_stats_workspace_bytes(int64_t n_rows, int M);
+int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
+                           int64_t n_rows, int K, int M, const float* bias /*nullable*/,
+                           const float* pro_scale /*nullable*/, const float* pro_shift /*nullable*/, float slope,
+                           double* sums2 /*[2M]*/, void* workspace, size_t workspace_bytes, void* stats_ws,
+                           size_t stats_ws_bytes, ddmp_stream stream);
+
 /* BatchNorm+LeakyReLU backward fused into the operand load of the GEMMs that consume dY (agg-first layers of the
  * engine; replaces ddmp_bn_bwd_apply_f32 + ddmp_gemm_nn_f32 + ddmp_gemm_tn_f32 of util/networks.py's autograd chain):
  *     dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0        (a, b, c1, c0 per column, from ddmp_bn_bwd_prepare_f32)

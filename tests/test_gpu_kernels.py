@@ -161,6 +161,23 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("n,K,M", [(777, 512, 512), (70001, 64, 256), (1000, 96, 384), (513, 256, 128), (130, 8, 32)])
+def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
+    """Statistics from the GEMM epilogue (panel shapes) or from the fallback pass == bn_stats of the stored output."""
+    from dual_dmp_amd import ops
+    if gemm_mode == 0 and M & (M - 1):
+        pytest.skip("the fallback pass (ddmp_bn_stats_f32) takes power-of-two widths only")
+    torch.manual_seed(n + M)
+    a, w, bias = torch.randn(n, K) + 0.3, torch.randn(M, K) / K ** 0.5, torch.randn(M)
+    sums = torch.zeros(2 * M, dtype=torch.float64, device=dev)
+    y = ops.gemm_nt_stats(a.to(dev), w.to(dev), sums, bias=bias.to(dev))
+    ref = a.double() @ w.double().t() + bias.double()
+    assert relerr(y, ref) < GEMM_TOL[gemm_mode]
+    yd = y.double().cpu()
+    assert relerr(sums[:M], yd.sum(0)) < 1e-6
+    assert relerr(sums[M:], (yd * yd).sum(0)) < 1e-6
+
+
 def test_gemm_transpose_detecting(dev, gemm_mode):
     """A = I with an asymmetric W: a swapped C-write would show."""
     from dual_dmp_amd import ops
