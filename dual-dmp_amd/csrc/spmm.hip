@@ -295,18 +295,34 @@ int launch_patch(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int
 // ------------------------------------------------------------------------------------------------
 // U neighbours per batch, NR rows per lane group per step: U*NR gathers in flight per lane
 // (vertex graph, degree 6+1: U = 8, NR = 1; face graph, degree 3+1: U = 4, NR = 2).
-template <int LANES, int U, int NR, bool PRO>
+// SL slabs per pass: a lane fetches SL float4 (SL * 128 bytes apart) per neighbour, so the per-neighbour work
+// (index / weight read from LDS, 64-bit address arithmetic, loop control) is paid once per SL * 16 bytes.
+// RED: the output is a gradient dZ that a BatchNorm+LeakyReLU backward consumes next; the epilogue also produces that
+// layer's column reductions (what bn_bwd_reduce computes from dZ and the layer's pre-BatchNorm output Yp):
+//     red[chunk][0][c] = sum_rows g,   red[chunk][1][c] = sum_rows g * (Yp - mean) * rstd,   g = dZ * lrelu'(a Yp + b)
+// float32 partials per 64-row chunk, summed in float64 by fpartials_reduce_kernel.  Costs one streaming read of Yp
+// here instead of a second pass over dZ and Yp.
+struct BnRed {
+    const float* Yp;
+    int64_t ldyp;
+    const float *scale, *shift, *mean, *rstd;
+    float* part;
+};
+
+template <int LANES, int U, int NR, bool PRO, int SL, bool RED = false>
 __global__ __launch_bounds__(256) void spmm_slab_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int chunks_per_xcd, int n_chunks) {
+    float slope, int chunks_per_xcd, int n_chunks, BnRed red = BnRed()) {
     constexpr int CS = LANES * 4;
     constexpr int RPW = 64 / LANES;
     constexpr int RPB = 4 * RPW;
     __shared__ int s_rowptr[kRB + 1];
     __shared__ int s_col[kMaxE];
     __shared__ float s_w[kMaxE];
+    __shared__ float s_red[RED ? 4 * 2 * CS : 1];                // [wave][which][channel of the slab]
+    static_assert(!RED || SL == 1, "the fused reduction walks one slab per pass");
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -329,25 +345,38 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LANES, sl = lane % LANES;
-    for (int c0 = 0; c0 < C; c0 += CS) {
+    for (int c0 = 0; c0 < C; c0 += CS * SL) {
         const int off = c0 + sl * 4;
-        float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO) {
-            pa = *reinterpret_cast<const float4*>(pscale + off);
-            pb = *reinterpret_cast<const float4*>(pshift + off);
+        float4 ra, rb, rmu, rrs, q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RED) {
+            ra = *reinterpret_cast<const float4*>(red.scale + off);
+            rb = *reinterpret_cast<const float4*>(red.shift + off);
+            rmu = *reinterpret_cast<const float4*>(red.mean + off);
+            rrs = *reinterpret_cast<const float4*>(red.rstd + off);
         }
-        const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 pa[SL], pb[SL], bs[SL];
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            pa[s] = make_float4(1.f, 1.f, 1.f, 1.f);
+            pb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PRO) {
+                pa[s] = *reinterpret_cast<const float4*>(pscale + off + s * CS);
+                pb[s] = *reinterpret_cast<const float4*>(pshift + off + s * CS);
+            }
+            bs[s] = bias ? *reinterpret_cast<const float4*>(bias + off + s * CS) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const float* xc = X + off;
         for (int lr0 = wave * RPW + grp; lr0 < nr; lr0 += RPB * NR) {
             int es[NR], ee[NR];
-            float4 acc[NR];
+            float4 acc[NR][SL];
             int more = 0;
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 const int lr = min(lr0 + q * RPB, nr - 1);
                 es[q] = s_rowptr[lr] - e0;
                 ee[q] = (lr0 + q * RPB < nr) ? s_rowptr[lr + 1] - e0 : es[q];     // rows past the chunk: empty
-                acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int s = 0; s < SL; ++s) acc[q][s] = make_float4(0.f, 0.f, 0.f, 0.f);
                 more |= (ee[q] > es[q]);
             }
             while (more) {
@@ -367,23 +396,29 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                         }
                         if (es[q] + k >= ee[q]) wj[q][k] = 0.f;
                     }
-                float4 v[NR][U];
+                float4 v[NR][U][SL];
 #pragma unroll
                 for (int q = 0; q < NR; ++q)
 #pragma unroll
-                    for (int k = 0; k < U; ++k) v[q][k] = *reinterpret_cast<const float4*>(xc + (int64_t)cj[q][k] * ldx);
+                    for (int k = 0; k < U; ++k) {
+                        const float* xr = xc + (int64_t)cj[q][k] * ldx;
+#pragma unroll
+                        for (int s = 0; s < SL; ++s) v[q][k][s] = *reinterpret_cast<const float4*>(xr + s * CS);
+                    }
                 more = 0;
 #pragma unroll
                 for (int q = 0; q < NR; ++q) {
 #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        float4 t = v[q][k];
-                        if (PRO) t = f4_affine_lrelu(t, pa, pb, slope);
-                        acc[q].x = fmaf(wj[q][k], t.x, acc[q].x);
-                        acc[q].y = fmaf(wj[q][k], t.y, acc[q].y);
-                        acc[q].z = fmaf(wj[q][k], t.z, acc[q].z);
-                        acc[q].w = fmaf(wj[q][k], t.w, acc[q].w);
-                    }
+                    for (int k = 0; k < U; ++k)
+#pragma unroll
+                        for (int s = 0; s < SL; ++s) {
+                            float4 t = v[q][k][s];
+                            if (PRO) t = f4_affine_lrelu(t, pa[s], pb[s], slope);
+                            acc[q][s].x = fmaf(wj[q][k], t.x, acc[q][s].x);
+                            acc[q][s].y = fmaf(wj[q][k], t.y, acc[q][s].y);
+                            acc[q][s].z = fmaf(wj[q][k], t.z, acc[q][s].z);
+                            acc[q][s].w = fmaf(wj[q][k], t.w, acc[q][s].w);
+                        }
                     es[q] = min(es[q] + U, ee[q]);
                     more |= (ee[q] > es[q]);
                 }
@@ -394,19 +429,97 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                 if (lr < nr) {
                     const int row = r0 + lr;
                     const float di = dinv[row];
-                    float4 o;
-                    o.x = fmaf(acc[q].x, di, bs.x);
-                    o.y = fmaf(acc[q].y, di, bs.y);
-                    o.z = fmaf(acc[q].z, di, bs.z);
-                    o.w = fmaf(acc[q].w, di, bs.w);
-                    *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + off) = o;
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) {
+                        float4 o;
+                        o.x = fmaf(acc[q][s].x, di, bs[s].x);
+                        o.y = fmaf(acc[q][s].y, di, bs[s].y);
+                        o.z = fmaf(acc[q][s].z, di, bs[s].z);
+                        o.w = fmaf(acc[q][s].w, di, bs[s].w);
+                        *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + off + s * CS) = o;
+                        if (RED) {
+                            const float4 y = *reinterpret_cast<const float4*>(red.Yp + (int64_t)row * red.ldyp + off);
+                            const float g0 = o.x * lrelu_grad(fmaf(y.x, ra.x, rb.x), slope);
+                            const float g1 = o.y * lrelu_grad(fmaf(y.y, ra.y, rb.y), slope);
+                            const float g2 = o.z * lrelu_grad(fmaf(y.z, ra.z, rb.z), slope);
+                            const float g3 = o.w * lrelu_grad(fmaf(y.w, ra.w, rb.w), slope);
+                            q0.x += g0; q0.y += g1; q0.z += g2; q0.w += g3;
+                            q1.x = fmaf(g0, (y.x - rmu.x) * rrs.x, q1.x);
+                            q1.y = fmaf(g1, (y.y - rmu.y) * rrs.y, q1.y);
+                            q1.z = fmaf(g2, (y.z - rmu.z) * rrs.z, q1.z);
+                            q1.w = fmaf(g3, (y.w - rmu.w) * rrs.w, q1.w);
+                        }
+                    }
                 }
+            }
+        }
+        if (RED) {                                               // rows of the chunk -> one partial per channel
+            float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int o = LANES; o < 64; o <<= 1) v[e] += __shfl_xor(v[e], o, 64);     // over the row groups of the wave
+            __syncthreads();                                     // previous slab's s_red has been consumed
+            if (grp == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s_red[(wave * 2 + 0) * CS + sl * 4 + e] = v[e];
+                    s_red[(wave * 2 + 1) * CS + sl * 4 + e] = v[4 + e];
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * CS) {
+                const int which = tid / CS, ch = tid % CS;
+                const float t = s_red[(0 * 2 + which) * CS + ch] + s_red[(1 * 2 + which) * CS + ch] +
+                                s_red[(2 * 2 + which) * CS + ch] + s_red[(3 * 2 + which) * CS + ch];
+                red.part[((int64_t)chunk * 2 + which) * C + c0 + ch] = t;
             }
         }
     }
 }
 
-template <int LANES, int U, int NR>
+// [groups][2][C] float32 partials -> sums[2C] float64.  32 columns x 8 group slices per workgroup.
+__global__ __launch_bounds__(256) void fpartials_reduce_kernel(const float* __restrict__ part, int groups, int C,
+                                                               double* __restrict__ sums) {
+    __shared__ double sm[2][256];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), slc = threadIdx.x >> 5;
+    double t0 = 0.0, t1 = 0.0;
+    if (c < C) {
+        int gi = slc;
+        for (; gi + 56 < groups; gi += 64) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = part[((int64_t)(gi + 8 * u) * 2) * C + c];
+                b[u] = part[((int64_t)(gi + 8 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t0 += (double)a[u];
+                t1 += (double)b[u];
+            }
+        }
+        for (; gi < groups; gi += 8) {
+            t0 += (double)part[((int64_t)gi * 2) * C + c];
+            t1 += (double)part[((int64_t)gi * 2 + 1) * C + c];
+        }
+    }
+    sm[0][threadIdx.x] = t0;
+    sm[1][threadIdx.x] = t1;
+    __syncthreads();
+    if (slc == 0 && c < C) {
+        double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            r0 += sm[0][u * 32 + threadIdx.x];
+            r1 += sm[1][u * 32 + threadIdx.x];
+        }
+        sums[c] = r0;
+        sums[C + c] = r1;
+    }
+}
+
+template <int LANES, int U, int NR, int SL = 1>
 int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
                 const float* ps, const float* psh, float slope, hipStream_t st) {
     const int n = (int)g->n_rows;
@@ -414,10 +527,10 @@ int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int6
     const int cpx = (int)cdiv(n_chunks, kXcd);
     dim3 grid(cpx * kXcd), block(256);
     if (ps)
-        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
+        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
     else
-        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, false>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
+        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, false, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -463,6 +576,14 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
         // 4 gathers in flight per lane measured best (8 in flight -- one batch of 8, or two rows x 4 -- was 3-5 %
         // slower: the kernel is bound by on-chip issue / L1 cost per gathered row, not by memory latency);
         // DDMP_SPMM=s1 selects the 8-in-flight forms for A/B runs
+        static int slabs = -1;                       // DDMP_SPMM_SL=1|2|4: slabs per pass (A/B)
+        if (slabs < 0) {
+            const char* e2 = getenv("DDMP_SPMM_SL");
+            slabs = e2 ? atoi(e2) : 1;
+        }
+        if (spmm_mode == 4 && slabs == 2 && C % 64 == 0) return launch_slab<8, 4, 1, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
+        if (spmm_mode == 4 && slabs == 4 && C % 128 == 0) return launch_slab<8, 4, 1, 4>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
+        if (spmm_mode == 4 && slabs == 22 && C % 64 == 0) return launch_slab<8, 2, 1, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
         if (spmm_mode == 4) return launch_slab<8, 4, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
         if (g->max_row_nnz <= 4) return launch_slab<8, 4, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
         return launch_slab<8, 8, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
@@ -499,6 +620,46 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
     else
         hipLaunchKernelGGL((spmm_scalar_kernel<false>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->dinv,
                            X, ldx, Y, ldy, (int)g->n_rows, C, bias, pro_scale, pro_shift, slope);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+
+// SpMM whose output dZ feeds a BatchNorm+LeakyReLU backward: also returns that layer's column reductions
+// (= ddmp_bn_bwd_reduce_f32(Y, Yp, ...)).  Fused into the slab kernel's epilogue where that kernel runs.
+extern "C" size_t ddmp_spmm_bnred_workspace_bytes(int64_t n_rows, int C) {
+    if (n_rows <= 0 || C <= 0) return 0;
+    const size_t fused = (size_t)ddmp::cdiv(n_rows, kRB) * 2 * (size_t)C * sizeof(float);
+    return std::max(fused, ddmp_colreduce_workspace_bytes(n_rows, C));
+}
+
+extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                                   const float* Yp, int64_t ldyp, const float* scale, const float* shift,
+                                   const float* mean, const float* rstd, float slope, double* sums2, void* ws,
+                                   size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && C > 0 && ldx >= C && ldy >= C && ldyp >= C);
+    ARG_TRY(X != Y);
+    if (ws_bytes < ddmp_spmm_bnred_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool fused = C % 32 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldyp % 4 == 0 && al16(X) && al16(Y) && al16(Yp) &&
+                       al16(scale) && al16(shift) && al16(mean) && al16(rstd) && al16(ws);
+    if (!fused) {
+        int rc = ddmp_spmm_f32(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, stream);
+        if (rc != DDMP_OK) return rc;
+        return ddmp_bn_bwd_reduce_f32(Y, ldy, Yp, ldyp, g->n_rows, C, scale, shift, mean, rstd, slope, sums2, ws, ws_bytes,
+                                      stream);
+    }
+    const int n = (int)g->n_rows;
+    const int n_chunks = (int)cdiv(n, kRB);
+    const int cpx = (int)cdiv(n_chunks, kXcd);
+    BnRed red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
+    hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
+                       g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       slope, cpx, n_chunks, red);
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(fpartials_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, n_chunks,
+                       C, sums2);
     LAUNCH_TRY();
     return DDMP_OK;
 }

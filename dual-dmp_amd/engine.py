@@ -237,13 +237,26 @@ class GcnEngine:
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
                      L.view(grads, "linear2.weight"), L.view(grads, "linear2.bias"), n_rows=n)
         cur = 1                                   # index of the work buffer holding dZ
+        have_sums = False
+        fuse_red = hasattr(ops, "spmm_bnred")
+
+        def spmm_to_dz(src, dst, l):
+            """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""
+            if fuse_red and l > 0:
+                ops.spmm_bnred(g, src, dst[:n], self.Y[l - 1], self.bn4[l - 1], self.sums)
+                return True
+            ops.spmm(g, src, out=dst[:n])
+            return False
+
         for l in range(11, -1, -1):
             i = l + 1
             co, ci = L.cout[l], L.cin_p[l]
             W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
             dW = L.view(grads, "conv%d.lin.weight" % i, true_shape=False)
             Y = self.Y[l]
-            ops.bn_bwd_reduce(dZ, Y, self.bn4[l], sums2=self.sums, n_rows=n)
+            if not have_sums:                                    # else: produced by the SpMM that wrote dZ
+                ops.bn_bwd_reduce(dZ, Y, self.bn4[l], sums2=self.sums, n_rows=n)
+            have_sums = False
             comm.all_reduce_sum(self.sums[: 2 * co])
             ops.bn_bwd_prepare(self.sums, self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % i),
                                L.view(grads, "bn%d.bias" % i), self.c10[:, :co])
@@ -258,7 +271,7 @@ class GcnEngine:
                 ops.gemm_nn_bnbwd(dZ, Y, W, self.bn4[l], self.c10[:, :co], out=dP, n_rows=n)
                 comm.halo_exchange(dP, n)
                 dZ = self._work(others[1], ci)
-                ops.spmm(g, dP, out=dZ[:n])
+                have_sums = spmm_to_dz(dP, dZ, l)
                 cur = others[1]
                 continue
             dY = self._work(others[0], co)
@@ -275,7 +288,7 @@ class GcnEngine:
                     ops.gemm_nn(dY, W, out=dP, n_rows=n)
                     comm.halo_exchange(dP, n)
                     dZ = self._work(others[1], ci)
-                    ops.spmm(g, dP, out=dZ[:n])
+                    have_sums = spmm_to_dz(dP, dZ, l)
                     cur = others[1]
             else:
                 comm.halo_exchange(dY, n)

@@ -213,6 +213,22 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
     return out
 
 
+def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
+    """out = spmm(g, x) (a gradient dZ) and sums2 = bn_bwd_reduce(out, yp, bn4) from the same kernel."""
+    x, ldx = _mat(x, "x")
+    out, ldy = _mat(out, "out")
+    yp, ldyp = _mat(yp, "yp")
+    C = x.shape[1]
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_spmm_bnred_workspace_bytes(g.n_rows, C), x.device)
+    alg = 3.0 * g.n_rows * C * 4 + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
+    with _timed("spmm", C, alg, 2.0 * g.nnz * C):
+        st = L.ddmp_spmm_bnred_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
+                                   _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_spmm_bnred_f32")
+    return out
+
+
 def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
     a, lda = _mat(a, "a")

@@ -201,6 +201,16 @@ int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm,
 int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
+/* ddmp_spmm_f32 (no bias, no prologue) whose output Y is a gradient dZ consumed next by a BatchNorm+LeakyReLU
+ * backward: also returns that layer's column reductions sums2 = ddmp_bn_bwd_reduce_f32(Y, Yp, scale, shift, mean,
+ * rstd) from the kernel's epilogue (float32 partials per 64-row chunk, summed in float64); other widths run the two
+ * calls one after the other. */
+size_t ddmp_spmm_bnred_workspace_bytes(int64_t n_rows, int C);
+int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                        const float* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
+                        const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace,
+                        size_t workspace_bytes, ddmp_stream stream);
+
 /* ddmp_gemm_nt_f32 that also returns the BatchNorm statistics of its output (float64 [2M]: column sums of Y and of
  * Y^2 over the n_rows rows = what ddmp_bn_stats_f32(Y) returns; GCNConv -> BatchNorm1d, util/networks.py:52-53).  The
  * row-panel kernel produces them in its epilogue (float32 partials per 64 rows, summed in float64); other shapes run

@@ -80,6 +80,25 @@ def test_spmm_matches_dense(dev, graphs, C, gname):
     assert relerr(y, ref) < 1e-6
 
 
+@pytest.mark.parametrize("C", [32, 256, 8])
+def test_spmm_with_bn_backward_reduce(dev, graphs, C):
+    """SpMM + the BatchNorm-backward column reductions of its output from one kernel == the two separate calls."""
+    from dual_dmp_amd import ops
+    for gname in graphs:
+        ei, n = graphs[gname]
+        torch.manual_seed(C + n)
+        x, yp = torch.randn(n, C), torch.randn(n, C) * 2 + 0.3
+        bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5]).to(dev)
+        g = ops.graph_for(ei.to(dev), n)
+        ref_y = ops.spmm(g, x.to(dev))
+        ref_s = ops.bn_bwd_reduce(ref_y, yp.to(dev), bn4)
+        out = torch.empty_like(ref_y)
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        ops.spmm_bnred(g, x.to(dev), out, yp.to(dev), bn4, sums)
+        assert torch.equal(out, ref_y)
+        assert relerr(sums, ref_s) < 1e-5, (gname, relerr(sums, ref_s))
+
+
 def test_spmm_multi_edges_and_self_loops(dev):
     from dual_dmp_amd import ops
     ei = torch.tensor([[0, 1, 1, 2, 2, 0, 1, 3, 3], [1, 0, 2, 1, 0, 2, 0, 3, 3]])
