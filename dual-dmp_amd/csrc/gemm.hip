@@ -321,7 +321,7 @@ bool tn_panel_enabled();
 TnPlan tn_plan(int64_t n_rows, int M, int K) {
     TnPlan p;
     p.T = (M >= 128 && K >= 128) ? 2 : 1;
-    if (M >= 256 && K >= 256 && tn_panel_enabled()) {
+    if (M >= 256 && K >= 256 && n_rows >= 65536 && tn_panel_enabled()) {
         p.T = 4;
         p.n_tiles_m = (int)cdiv(M, 256);
         p.n_tiles_k = (int)cdiv(K, 256);
@@ -426,8 +426,12 @@ static bool panel_enabled() {
     }
     return e == 1;
 }
-static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
-    return panel_enabled() && KD % 32 == 0 && KD >= 64 && MD % 4 == 0 && MD > 128 && MD <= 512 && ws &&
+// Row panels leave CUs idle on small inputs (one 512-thread workgroup per 128/256 rows): measured better from ~25k
+// rows (50k-face mesh 4.74 vs 5.02 ms/iteration, 13k-face mesh 4.08 vs 3.03); the wgrad panels from ~64k rows.
+constexpr int64_t kPanelMinRows = 20000, kTnPanelMinRows = 65536;
+static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes,
+                            int64_t n_rows) {
+    return panel_enabled() && n_rows >= kPanelMinRows && KD % 32 == 0 && KD >= 64 && MD % 4 == 0 && MD > 128 && MD <= 512 && ws &&
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
 }
@@ -524,7 +528,7 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int TN = M > 64 ? 2 : 1;
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
-    if (gemm_mode() != 0 && !(pro_scale && K > 512) && panel_ok(K, M, Y, ldy, workspace, workspace_bytes)) {
+    if (gemm_mode() != 0 && !(pro_scale && K > 512) && panel_ok(K, M, Y, ldy, workspace, workspace_bytes, n_rows)) {
         if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st);
         else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st);
         LAUNCH_TRY();
@@ -583,7 +587,7 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
     // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
     // in its row-major (NT) form on the planes
-    if (gemm_mode() != 0 && panel_ok(M, K, Y, ldy, workspace, workspace_bytes)) {
+    if (gemm_mode() != 0 && panel_ok(M, K, Y, ldy, workspace, workspace_bytes, n_rows)) {
         launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, st);
         LAUNCH_TRY();
         return DDMP_OK;
@@ -702,8 +706,8 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
 
 
 // ---- BatchNorm+LeakyReLU backward fused into the operand load of the two GEMMs that consume dY (agg-first layers)
-extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin) {
-    if (gemm_mode() == 0 || !panel_enabled() || !tn_panel_enabled()) return 0;
+extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows) {
+    if (gemm_mode() == 0 || !panel_enabled() || !tn_panel_enabled() || n_rows < kTnPanelMinRows) return 0;
     const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin > 128 && cin <= 512;
     const bool tn = cout >= 256 && cin >= 256 && cout % 4 == 0;
     return (nn && tn) ? 1 : 0;
@@ -717,7 +721,7 @@ extern "C" int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     ARG_TRY(dZ && Yb && W && out && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
     ARG_TRY(lddz % 4 == 0 && ldyb % 4 == 0 && ldw % 4 == 0 && lddz >= M && ldyb >= M && ldw >= K && ld_out >= K);
     ARG_TRY(aligned16(dZ) && aligned16(Yb) && aligned16(W));
-    if (!ddmp_gemm_bnbwd_supported(M, K) || !panel_ok(M, K, out, ld_out, workspace, workspace_bytes)) return DDMP_EINVAL;
+    if (!ddmp_gemm_bnbwd_supported(M, K, n_rows) || !panel_ok(M, K, out, ld_out, workspace, workspace_bytes, n_rows)) return DDMP_EINVAL;
     launch_panel<2>(gemm_mode(), dZ, lddz, Yb, ldyb, W, ldw, 1, workspace, out, ld_out, (int)n_rows, M, K, nullptr, a, b,
                     c1, c0, slope, (hipStream_t)stream);
     LAUNCH_TRY();
@@ -733,7 +737,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     ARG_TRY(dZ && Yb && Z && dW && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lddz >= M && ldyb >= M && ldz >= K && lddw >= K);
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
-    if (!ddmp_gemm_bnbwd_supported(M, K)) return DDMP_EINVAL;
+    if (!ddmp_gemm_bnbwd_supported(M, K, n_rows)) return DDMP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     TnPlan p = tn_plan(n_rows, M, K);
     if (p.T != 4) return DDMP_EINVAL;
@@ -780,7 +784,7 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
     const bool fused = A && W && Y && n_rows > 0 && n_rows < INT32_MAX && K > 0 && M > 0 && K % 4 == 0 && lda % 4 == 0 &&
                        ldw % 4 == 0 && lda >= K && ldw >= K && ldy >= M && aligned16(A) && aligned16(W) &&
                        (pro_scale == nullptr) == (pro_shift == nullptr) && gemm_mode() != 0 && !(pro_scale && K > 512) &&
-                       panel_ok(K, M, Y, ldy, workspace, workspace_bytes);
+                       panel_ok(K, M, Y, ldy, workspace, workspace_bytes, n_rows);
     if (fused) {
         hipStream_t st = (hipStream_t)stream;
         if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (float*)stats_ws, sums2);

@@ -154,7 +154,7 @@ class GcnEngine:
         # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
         self.agg_first = [L.cin_p[l] <= L.cout[l] for l in range(12)]
         supported = getattr(ops, "gemm_bnbwd_supported", None)
-        self.fuse_bnbwd = [bool(supported) and l > 0 and self.agg_first[l] and supported(L.cout[l], L.cin_p[l])
+        self.fuse_bnbwd = [bool(supported) and l > 0 and self.agg_first[l] and supported(L.cout[l], L.cin_p[l], self.n_rows)
                            for l in range(12)]
         cmax = max(L.cout)
         nc = self.n_cols

@@ -313,9 +313,9 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
     return out
 
 
-def gemm_bnbwd_supported(cout, cin):
-    """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout in the current GEMM mode?"""
-    return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin)))
+def gemm_bnbwd_supported(cout, cin, n_rows):
+    """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout over n_rows rows in the current GEMM mode?"""
+    return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin), int(n_rows)))
 
 
 def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
