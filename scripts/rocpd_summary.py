@@ -7,6 +7,13 @@ import sys
 
 
 def short(name):
+    if name.startswith("_Z"):                       # rocprofv3 leaves names with __bf16 parameters mangled
+        import subprocess
+        try:
+            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name.split(".kd")[0]], capture_output=True,
+                                  text=True, timeout=10).stdout.strip() or name
+        except Exception:
+            pass
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"void ", "", name)
     return name[:110]
