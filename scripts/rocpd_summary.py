@@ -8,12 +8,10 @@ import sys
 
 def short(name):
     if name.startswith("_Z"):                       # rocprofv3 leaves names with __bf16 parameters mangled
-        import subprocess
-        try:
-            name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name.split(".kd")[0]], capture_output=True,
-                                  text=True, timeout=10).stdout.strip() or name
-        except Exception:
-            pass
+        m = re.match(r"_ZN12_GLOBAL__N_1\d+([A-Za-z_0-9]+?)I((?:L[ib]\d+E)+)E", name)
+        if m:
+            args = re.findall(r"L([ib])(\d+)E", m.group(2))
+            name = "%s<%s>(...)" % (m.group(1), ", ".join(a if t == "i" else ("true" if a == "1" else "false") for t, a in args))
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"void ", "", name)
     return name[:110]
