@@ -462,9 +462,10 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         if (mode == 6) DDMP_PANEL(4, 2, 3); else DDMP_PANEL(4, 2, 2);
     }
 #undef DDMP_PANEL
-    if (stats && sums)
-        hipLaunchKernelGGL(panel_stats_reduce_kernel, dim3((unsigned)ddmp::cdiv(MD, 32)), dim3(256), 0, st, stats,
-                           n_row_tiles * WR, MP, MD, sums);
+    if (stats && sums) {
+        const size_t pbytes = ((size_t)n_row_tiles * WR * 2 * MP * sizeof(float) + 255) / 256 * 256;
+        fpartials_reduce(stats, n_row_tiles * WR, MP, MD, (double*)((char*)stats + pbytes), sums, st);
+    }
 }
 
 static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes) {
@@ -770,7 +771,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
 //      fused into the row-panel kernel's epilogue where that kernel runs, otherwise GEMM + ddmp_bn_stats_f32
 extern "C" size_t ddmp_gemm_nt_stats_workspace_bytes(int64_t n_rows, int M) {
     if (n_rows <= 0 || M <= 0) return 0;
-    const size_t fused = (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(float);
+    const size_t fused = (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(float) + 256 + fpartials_mid_bytes(512);
     return std::max(fused, ddmp_colreduce_workspace_bytes(n_rows, M));
 }
 

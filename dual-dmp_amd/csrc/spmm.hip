@@ -300,7 +300,7 @@ int launch_patch(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int
 // RED: the output is a gradient dZ that a BatchNorm+LeakyReLU backward consumes next; the epilogue also produces that
 // layer's column reductions (what bn_bwd_reduce computes from dZ and the layer's pre-BatchNorm output Yp):
 //     red[chunk][0][c] = sum_rows g,   red[chunk][1][c] = sum_rows g * (Yp - mean) * rstd,   g = dZ * lrelu'(a Yp + b)
-// float32 partials per 64-row chunk, summed in float64 by fpartials_reduce_kernel.  Costs one streaming read of Yp
+// float32 partials per wave and 64-row chunk, summed in float64 by fpartials_reduce_kernel.  Costs one streaming read of Yp
 // here instead of a second pass over dZ and Yp.
 struct BnRed {
     const float* Yp;
@@ -321,7 +321,6 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
     __shared__ int s_rowptr[kRB + 1];
     __shared__ int s_col[kMaxE];
     __shared__ float s_w[kMaxE];
-    __shared__ float s_red[RED ? 4 * 2 * CS : 1];                // [wave][which][channel of the slab]
     static_assert(!RED || SL == 1, "the fused reduction walks one slab per pass");
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
@@ -453,71 +452,22 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                 }
             }
         }
-        if (RED) {                                               // rows of the chunk -> one partial per channel
-            float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
+        if (RED) {                                               // this wave's rows -> one partial per channel and wave
+            float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};      // (no workgroup barrier: the slab loop
+#pragma unroll                                                                  //  of the four waves stays decoupled)
             for (int e = 0; e < 8; ++e)
 #pragma unroll
                 for (int o = LANES; o < 64; o <<= 1) v[e] += __shfl_xor(v[e], o, 64);     // over the row groups of the wave
-            __syncthreads();                                     // previous slab's s_red has been consumed
             if (grp == 0) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s_red[(wave * 2 + 0) * CS + sl * 4 + e] = v[e];
-                    s_red[(wave * 2 + 1) * CS + sl * 4 + e] = v[4 + e];
-                }
-            }
-            __syncthreads();
-            if (tid < 2 * CS) {
-                const int which = tid / CS, ch = tid % CS;
-                const float t = s_red[(0 * 2 + which) * CS + ch] + s_red[(1 * 2 + which) * CS + ch] +
-                                s_red[(2 * 2 + which) * CS + ch] + s_red[(3 * 2 + which) * CS + ch];
-                red.part[((int64_t)chunk * 2 + which) * C + c0 + ch] = t;
+                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
+                *reinterpret_cast<float4*>(pp) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(pp + C) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
     }
 }
 
-// [groups][2][C] float32 partials -> sums[2C] float64.  32 columns x 8 group slices per workgroup.
-__global__ __launch_bounds__(256) void fpartials_reduce_kernel(const float* __restrict__ part, int groups, int C,
-                                                               double* __restrict__ sums) {
-    __shared__ double sm[2][256];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), slc = threadIdx.x >> 5;
-    double t0 = 0.0, t1 = 0.0;
-    if (c < C) {
-        int gi = slc;
-        for (; gi + 56 < groups; gi += 64) {
-            float a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                a[u] = part[((int64_t)(gi + 8 * u) * 2) * C + c];
-                b[u] = part[((int64_t)(gi + 8 * u) * 2 + 1) * C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                t0 += (double)a[u];
-                t1 += (double)b[u];
-            }
-        }
-        for (; gi < groups; gi += 8) {
-            t0 += (double)part[((int64_t)gi * 2) * C + c];
-            t1 += (double)part[((int64_t)gi * 2 + 1) * C + c];
-        }
-    }
-    sm[0][threadIdx.x] = t0;
-    sm[1][threadIdx.x] = t1;
-    __syncthreads();
-    if (slc == 0 && c < C) {
-        double r0 = 0.0, r1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            r0 += sm[0][u * 32 + threadIdx.x];
-            r1 += sm[1][u * 32 + threadIdx.x];
-        }
-        sums[c] = r0;
-        sums[C + c] = r1;
-    }
-}
+#include "fpartials.inc"
 
 template <int LANES, int U, int NR, int SL = 1>
 int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
@@ -629,7 +579,7 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
 // (= ddmp_bn_bwd_reduce_f32(Y, Yp, ...)).  Fused into the slab kernel's epilogue where that kernel runs.
 extern "C" size_t ddmp_spmm_bnred_workspace_bytes(int64_t n_rows, int C) {
     if (n_rows <= 0 || C <= 0) return 0;
-    const size_t fused = (size_t)ddmp::cdiv(n_rows, kRB) * 2 * (size_t)C * sizeof(float);
+    const size_t fused = (size_t)ddmp::cdiv(n_rows, kRB) * 4 * 2 * (size_t)C * sizeof(float) + 256 + fpartials_mid_bytes(C);
     return std::max(fused, ddmp_colreduce_workspace_bytes(n_rows, C));
 }
 
@@ -658,8 +608,8 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
                        g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        slope, cpx, n_chunks, red);
     LAUNCH_TRY();
-    hipLaunchKernelGGL(fpartials_reduce_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, (const float*)ws, n_chunks,
-                       C, sums2);
+    const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
+    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
     LAUNCH_TRY();
     return DDMP_OK;
 }

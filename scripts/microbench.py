@@ -60,6 +60,13 @@ if a.what in ("spmm", "all"):
             alg = 2.0 * nn_ * C * 4 + 4.0 * g.nnz + 8.0 * nn_
             print("spmm %s N=%d C=%3d  %8.0f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)  gather-logical %.1f GB/s" % (
                 gname, nn_, C, us, alg / us / 1e3, alg / us / 1e3 / 80.0, (g.nnz * C * 4.0 + nn_ * C * 4.0) / us / 1e3))
+            if C >= 128:
+                sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev)
+                us_p = timeit(lambda: ops.spmm(g, X, out=Y, pro=(sc, sh)))
+                bn4 = torch.rand(4, C, device=dev) + 0.5; sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+                Yp = torch.randn(nn_, C, device=dev)
+                us_r = timeit(lambda: ops.spmm_bnred(g, X, Y, Yp, bn4, sums))
+                print("     +prologue %8.0f us (x%.2f)   +bn-backward reduce %8.0f us (x%.2f)" % (us_p, us_p / us, us_r, us_r / us))
 
 if a.what in ("bn", "all"):
     for C in (512, 256):
