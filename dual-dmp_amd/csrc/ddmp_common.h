@@ -82,4 +82,11 @@ struct ddmp_graph {
     int32_t* col;       // device [nnz]
     float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
     int max_row_nnz;
+    // per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR entry, the index of its
+    // column in that list -- what spmm_patch_dma_kernel stages through LDS (spmm.hip)
+    int32_t* pl_ptr;    // device [n_chunks + 1]
+    int32_t* pl_col;    // device [pl_ptr[n_chunks]]
+    uint16_t* lcol;     // device [nnz]
+    int max_patch;      // largest patch (0: tables not built)
 };
+namespace ddmp { constexpr int kChunkRows = 64; }

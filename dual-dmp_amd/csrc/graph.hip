@@ -7,6 +7,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 extern "C" int ddmp_abi_version(void) { return DDMP_ABI_VERSION; }
 
@@ -106,6 +107,35 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
     if (g->nnz > 0 &&
         (e = hipMemcpy(g->col, col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    {   // patch tables (see ddmp_graph): skipped when the rows of a chunk fan out too far (unordered numbering)
+        const int64_t n_chunks = (n_rows + ddmp::kChunkRows - 1) / ddmp::kChunkRows;
+        std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, tmp;
+        std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1));
+        int max_patch = 0;
+        const char* pe = getenv("DDMP_SPMM_PATCH");
+        bool ok = g->nnz > 0 && pe && atoi(pe) == 1;      // tables only for the experimental patch kernel
+        for (int64_t c = 0; c < n_chunks && ok; ++c) {
+            const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
+            tmp.assign(col + rowptr[r0], col + rowptr[r1]);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            if (tmp.size() > 4096) { ok = false; break; }
+            max_patch = std::max(max_patch, (int)tmp.size());
+            for (int64_t e2 = rowptr[r0]; e2 < rowptr[r1]; ++e2)
+                lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
+            pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
+            pl_ptr[(size_t)c + 1] = (int32_t)pl_col.size();
+        }
+        if (ok) {
+            if ((e = hipMalloc((void**)&g->pl_ptr, sizeof(int32_t) * pl_ptr.size())) != hipSuccess) goto fail;
+            if ((e = hipMalloc((void**)&g->pl_col, sizeof(int32_t) * std::max<size_t>(pl_col.size(), 1))) != hipSuccess) goto fail;
+            if ((e = hipMalloc((void**)&g->lcol, sizeof(uint16_t) * lcol.size())) != hipSuccess) goto fail;
+            if ((e = hipMemcpy(g->pl_ptr, pl_ptr.data(), sizeof(int32_t) * pl_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+            if ((e = hipMemcpy(g->pl_col, pl_col.data(), sizeof(int32_t) * pl_col.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+            if ((e = hipMemcpy(g->lcol, lcol.data(), sizeof(uint16_t) * lcol.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+            g->max_patch = max_patch;
+        }
+    }
     *out = g;
     return DDMP_OK;
 fail:
@@ -153,6 +183,9 @@ extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->col) (void)hipFree(g->col);
     if (g->dinv) (void)hipFree(g->dinv);
+    if (g->pl_ptr) (void)hipFree(g->pl_ptr);
+    if (g->pl_col) (void)hipFree(g->pl_col);
+    if (g->lcol) (void)hipFree(g->lcol);
     delete g;
     return DDMP_OK;
 }
