@@ -143,3 +143,53 @@ def test_training_iteration_invariances_at_1m(big):
         assert abs(loss - base[0][0]) <= 1e-6 * abs(base[0][0]), (loss, base[0][0])
         assert float((pos - base[0][1]).abs().max()) < 5e-5
     assert res[0][2] + res[1][2] == len(noisy.vs)
+
+
+def test_fused_engine_matches_unfused_kernels_at_140k():
+    """Above 64k rows the engine takes its fused routes (BatchNorm statistics from the GEMM epilogue, BatchNorm backward
+    rebuilt on the dgrad/wgrad operand loads, backward reductions from the SpMM epilogue, row-panel GEMMs).  GEMM mode 0
+    (f32-input MFMA kernels) has none of the panel kernels, so the same step through both modes checks the fused
+    bookkeeping (buffer rotation, which sums belong to which layer) end to end: outputs and every gradient agree to
+    float32 GEMM rounding."""
+    from dual_dmp_amd import ops, synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    dev = torch.device("cuda:0")
+    v, f = synth.torus(380, 190)                       # 144,400 faces / 72,200 vertices: both nets above the thresholds
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+    data.to(dev)
+    assert len(noisy.vs) >= 65536
+    old = ops.get_gemm_mode()
+    res = {}
+    try:
+        for mode in (6, 0):
+            ops.set_gemm_mode(mode)
+            torch.manual_seed(3)
+            out = []
+            for Net, n_out in ((PosNet, len(noisy.vs)), (NormalNet, len(noisy.faces))):
+                net = Net(dev)
+                with torch.no_grad():                 # non-trivial BatchNorm parameters and conv biases
+                    for name, view in net.named_views().items():
+                        if name.startswith("bn") and name.endswith("weight"):
+                            view.uniform_(0.5, 1.5)
+                        elif name.endswith("bias"):
+                            view.normal_(std=0.1)
+                eng = net._get_engine(data)
+                if mode == 6:
+                    assert any(eng.fuse_bnbwd), "the fused BatchNorm-backward route must be active at this size"
+                o = eng.forward(net.arena.data, update_running=False)
+                torch.manual_seed(17)
+                dout = torch.randn(n_out, 3, device=dev)
+                grads = torch.zeros_like(net.arena.data)
+                eng.backward(net.arena.data, grads, dout)
+                out.append((o.clone(), {k: net.layout.view(grads, k).clone() for k, *_ in net.layout.entries}))
+            res[mode] = out
+    finally:
+        ops.set_gemm_mode(old)
+    for (o6, g6), (o0, g0) in zip(res[6], res[0]):
+        assert rel(o6, o0) < 2e-5
+        for k in g6:
+            if k.startswith("conv") and k.endswith(".bias"):
+                continue                              # analytically zero (fused route: exactly 0; unfused: rounding noise)
+            assert rel(g6[k], g0[k]) < 5e-3, (k, rel(g6[k], g0[k]))
