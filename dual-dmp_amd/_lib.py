@@ -75,6 +75,9 @@ def lib():
         raise DdmpError(
             "HIP extension not built: %s is missing.  Run `python -c \"import __graft_entry__ as g; g.build()\"` "
             "or `make -C dual-dmp_amd/csrc`.  There is no CPU fallback for the product path." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64: load it FIRST so that libddmp_hip.so binds to the same HIP runtime (two
+    # runtimes in one process do not share devices or streams: hipMalloc then fails with "no ROCm-capable device")
+    import torch  # noqa: F401
     try:
         handle = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
