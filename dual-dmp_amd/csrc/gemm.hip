@@ -431,7 +431,8 @@ static bool panel_enabled() {
 constexpr int64_t kPanelMinRows = 20000, kTnPanelMinRows = 65536;
 static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes,
                             int64_t n_rows) {
-    return panel_enabled() && n_rows >= kPanelMinRows && KD % 32 == 0 && KD >= 64 && MD % 4 == 0 && MD > 128 && MD <= 512 && ws &&
+    return panel_enabled() && n_rows >= kPanelMinRows && KD % 32 == 0 && KD >= 32 && (KD >= 64 || MD <= 128) &&
+           MD % 4 == 0 && MD >= 16 && MD <= 512 && ws &&
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
 }
@@ -440,8 +441,10 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
                          int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
                          const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
                          float slope, hipStream_t st, float* stats = nullptr, double* sums = nullptr) {
-    const int WC = MD > 256 ? 4 : 2, WR = 8 / WC;
-    const int MP = 128 * WC, BMR = 64 * WR;
+    // wide outputs: 128 x 512 | 256 x 256 blocks (64 x 128 per wave); narrow outputs (MD <= 128): 512-row blocks, 64 x 32 NJ
+    const int WC = MD > 256 ? 4 : MD > 128 ? 2 : 1, WR = 8 / WC;
+    const int NJ = MD > 128 ? 4 : MD > 64 ? 4 : MD > 32 ? 2 : 1;
+    const int MP = 32 * NJ * WC, BMR = 64 * WR;
     const int n_row_tiles = (int)ddmp::cdiv(n_rows, BMR);
     {
         const int64_t total = (int64_t)MP * KD;
@@ -453,13 +456,21 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
     }
     dim3 grid((unsigned)std::min(n_row_tiles, device_cus())), block(512);
     const __bf16* Bp = (const __bf16*)planes;
-#define DDMP_PANEL(WR_, WC_, NT_)                                                                                \
-    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy,   \
+#define DDMP_PANEL(WR_, WC_, NT_, NJ_)                                                                            \
+    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM, NJ_>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy, \
                        n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats)
     if (WC == 4) {
-        if (mode == 6) DDMP_PANEL(2, 4, 3); else DDMP_PANEL(2, 4, 2);
-    } else {
-        if (mode == 6) DDMP_PANEL(4, 2, 3); else DDMP_PANEL(4, 2, 2);
+        if (mode == 6) DDMP_PANEL(2, 4, 3, 4); else DDMP_PANEL(2, 4, 2, 4);
+    } else if (WC == 2) {
+        if (mode == 6) DDMP_PANEL(4, 2, 3, 4); else DDMP_PANEL(4, 2, 2, 4);
+    } else if constexpr (PM != 2) {                  // (the fused BatchNorm-backward form exists for wide outputs only)
+        if (NJ == 4) {
+            if (mode == 6) DDMP_PANEL(8, 1, 3, 4); else DDMP_PANEL(8, 1, 2, 4);
+        } else if (NJ == 2) {
+            if (mode == 6) DDMP_PANEL(8, 1, 3, 2); else DDMP_PANEL(8, 1, 2, 2);
+        } else {
+            if (mode == 6) DDMP_PANEL(8, 1, 3, 1); else DDMP_PANEL(8, 1, 2, 1);
+        }
     }
 #undef DDMP_PANEL
     if (stats && sums) {

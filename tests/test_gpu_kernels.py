@@ -128,6 +128,8 @@ GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6}
                                    # row-panel kernels: padded column panels (M < 128*WC), short K, ragged row tiles,
                                    # and more row tiles than CUs (the persistent loop crosses tile boundaries)
                                    (21000, 96, 384), (20300, 64, 260), (66500, 320, 384), (70001, 64, 256),
+                                   # narrow-output row panels (512-row blocks): M <= 32 | 64 | 128, K = 32 .. 256
+                                   (20500, 32, 64), (33000, 64, 32), (21001, 256, 128), (25000, 128, 20), (20100, 64, 100),
                                    (40000, 256, 512)])
 def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
     from dual_dmp_amd import ops
@@ -180,7 +182,8 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
 
 
-@pytest.mark.parametrize("n,K,M", [(20777, 512, 512), (70001, 64, 256), (21000, 96, 384), (513, 256, 128), (130, 8, 32)])
+@pytest.mark.parametrize("n,K,M", [(20777, 512, 512), (70001, 64, 256), (21000, 96, 384), (513, 256, 128), (130, 8, 32),
+                                   (30001, 64, 128), (20480, 32, 64), (22222, 128, 32)])
 def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
     """Statistics from the GEMM epilogue (panel shapes) or from the fallback pass == bn_stats of the stored output."""
     from dual_dmp_amd import ops
