@@ -68,7 +68,7 @@ def test_gemm_identities_at_1m():
     ones = torch.ones(n, 4, device=dev)
     dw = ops.gemm_tn(ones, a)                                                        # [4, K] = column sums
     cs = ops.colsum(a)
-    assert rel(dw[0], cs) < 1e-6 and torch.equal(dw[0], dw[3])
+    assert rel(dw[0], cs) < 3e-6 and torch.equal(dw[0], dw[3])     # float32 accumulation over 1M rows per split
     # tall-skinny associativity against float64 on a row sample
     w = torch.randn(512, K, device=dev) / 16
     y = ops.gemm_nt(a, w)
@@ -160,6 +160,8 @@ def test_fused_engine_matches_unfused_kernels_at_140k():
     data = dataset_from_meshes(noisy, smooth)
     data.to(dev)
     assert len(noisy.vs) >= 65536
+    if not ops.gemm_bnbwd_supported(512, 256, len(noisy.vs)):
+        pytest.skip("fused routes disabled in this configuration (DDMP_GEMM_PANEL=0 / GEMM mode 0)")
     old = ops.get_gemm_mode()
     res = {}
     try:
