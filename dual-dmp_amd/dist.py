@@ -142,6 +142,59 @@ class GraphComm:
     def all_reduce_sum(self, t: torch.Tensor):
         return self.backend.all_reduce_sum(t)
 
+    # ---- asynchronous forms: start the collective, return a handle (or None) to wait on before the data is used
+    def start_halo(self, t: torch.Tensor, n_rows: int):
+        p = self.plan
+        assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
+        send = t[:n_rows].index_select(0, self.send_idx)
+        recv = t[n_rows:p.n_cols]
+        start = getattr(self.backend, "all_to_all_start", None)
+        if start is None:
+            self.backend.all_to_all(recv, send, p.recv_counts, p.send_counts)
+            return None
+        return start(recv, send, p.recv_counts, p.send_counts)
+
+    def start_all_reduce(self, t: torch.Tensor):
+        start = getattr(self.backend, "all_reduce_start", None)
+        if start is None:
+            self.backend.all_reduce_sum(t)
+            return None
+        return start(t)
+
+
+class _Pending:
+    """A started torch.distributed collective; keeps its buffers alive until it has been waited for."""
+
+    def __init__(self, work, *keep):
+        self.work, self.keep = work, keep
+
+    def wait(self):
+        self.work.wait()
+        self.keep = None
+
+
+def interleave(a, b):
+    """Run two step generators (GcnEngine.forward_steps / backward_steps) alternately: each runs until it STARTS a
+    collective, then the other one gets the device while that collective is in flight.  Every rank executes the same
+    sequence, so the collectives are issued in the same order everywhere."""
+    ha = hb = None
+    done_a = done_b = False
+    while not (done_a and done_b):
+        if not done_a:
+            if ha is not None:
+                ha.wait()
+            try:
+                ha = next(a)
+            except StopIteration:
+                done_a, ha = True, None
+        if not done_b:
+            if hb is not None:
+                hb.wait()
+            try:
+                hb = next(b)
+            except StopIteration:
+                done_b, hb = True, None
+
 
 class TorchDistComm:
     """torch.distributed backend: "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests."""
@@ -158,6 +211,14 @@ class TorchDistComm:
     def all_reduce_sum(self, t):
         self.dist.all_reduce(t, group=self.group)
         return t
+
+    def all_to_all_start(self, recv, send, recv_counts, send_counts):
+        work = self.dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                           group=self.group, async_op=True)
+        return _Pending(work, recv, send)
+
+    def all_reduce_start(self, t):
+        return _Pending(self.dist.all_reduce(t, group=self.group, async_op=True), t)
 
     def barrier(self):
         self.dist.barrier(group=self.group)
@@ -280,6 +341,9 @@ class DistributedTrainer:
         self.epoch = 0
         self.t = 0
         self.lossbuf = None
+        # DDMP_DIST_INTERLEAVE=0: run the two nets one after the other with blocking collectives (A/B, fallback)
+        import os
+        self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "1") != "0"
 
     def barrier(self):
         self.backend.barrier()
@@ -295,8 +359,14 @@ class DistributedTrainer:
         V = self.sd.V
         pa, na = self.posnet.arena.data, self.normnet.arena.data
         pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
-        pos_loc = self.peng.forward(pa, update_running=True)
-        norm_loc = self.neng.forward(na, update_running=True)
+        # the two nets alternate at their collectives: one net's halo exchange / BatchNorm all-reduce is in flight
+        # while the other net's kernels run
+        if self.interleaved:
+            interleave(self.peng.forward_steps(pa, update_running=True), self.neng.forward_steps(na, update_running=True))
+        else:
+            self.peng.forward(pa, update_running=True)
+            self.neng.forward(na, update_running=True)
+        pos_loc, norm_loc = self.peng.result, self.neng.result
         self.full.zero_()
         self.full[:V].index_copy_(0, self.owned_v, pos_loc)
         self.full[V:].index_copy_(0, self.owned_f, norm_loc)
@@ -304,8 +374,12 @@ class DistributedTrainer:
         pos, norm = self.full[:V], self.full[V:]
         gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
         lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
-        self.peng.backward(pa, pg, dpos.index_select(0, self.owned_v))
-        self.neng.backward(na, ng, dnorm.index_select(0, self.owned_f))
+        if self.interleaved:
+            interleave(self.peng.backward_steps(pa, pg, dpos.index_select(0, self.owned_v)),
+                       self.neng.backward_steps(na, ng, dnorm.index_select(0, self.owned_f)))
+        else:
+            self.peng.backward(pa, pg, dpos.index_select(0, self.owned_v))
+            self.neng.backward(na, ng, dnorm.index_select(0, self.owned_f))
         self.posnet._reduce_grads()
         self.normnet._reduce_grads()
         o.grad_sumsq(ng, out=self.sumsq)

@@ -51,6 +51,13 @@ class NoComm:
     def all_reduce_sum(self, t):
         return t
 
+    # asynchronous forms (see GcnEngine.forward_steps): return a handle with .wait(), or None when there is nothing to wait for
+    def start_halo(self, t, n_rows):
+        return None
+
+    def start_all_reduce(self, t):
+        return None
+
 
 class ArenaLayout:
     """Offsets (in floats) of every parameter tensor inside the flat arena."""
@@ -185,7 +192,26 @@ class GcnEngine:
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _drain(steps):
+        for h in steps:
+            if h is not None:
+                h.wait()
+
     def forward(self, params: torch.Tensor, update_running: bool = True) -> torch.Tensor:
+        self._drain(self.forward_steps(params, update_running))
+        return self.result
+
+    def backward(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+        """Overwrites ``grads`` (same layout as ``params``) with d loss / d params for the last forward."""
+        self._drain(self.backward_steps(params, grads, dout))
+        return grads
+
+    def forward_steps(self, params: torch.Tensor, update_running: bool = True):
+        """The forward pass as a generator that yields at every collective it STARTS (halo exchange, BatchNorm
+        statistics all-reduce): the caller waits on the handle before resuming.  A multi-device trainer runs the
+        two nets' generators alternately, so that one net's collective is in flight while the other net computes
+        (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         X, pro = self.x0, None
         for l in range(12):
@@ -197,7 +223,7 @@ class GcnEngine:
                 P = self.P[l]
                 if l > 0 or not self._p1_ready:
                     if l > 0:
-                        comm.halo_exchange(X, n)
+                        yield comm.start_halo(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
                     self._p1_ready = True
                 if hasattr(ops, "gemm_nt_stats"):                # BatchNorm statistics from the GEMM epilogue
@@ -208,10 +234,10 @@ class GcnEngine:
             else:
                 H = self._work(0, L.cout[l])
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n)
-                comm.halo_exchange(H, n)
+                yield comm.start_halo(H, n)
                 ops.spmm(g, H, out=Y[:n], bias=b)
                 ops.bn_stats(Y, sums=self.sums, n_rows=n)
-            comm.all_reduce_sum(self.sums[: 2 * L.cout[l]])
+            yield comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
             ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
                            self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
             X, pro = Y, (self.bn4[l][0], self.bn4[l][1])
@@ -220,14 +246,14 @@ class GcnEngine:
         ops.head_fwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
                      L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, self.x_pos,
                      self.out, n_rows=n)
+        self.result = self.out
         if self.inv is not None:
             torch.index_select(self.out, 0, self.inv, out=self.out_orig)
-            return self.out_orig
-        return self.out
+            self.result = self.out_orig
 
     # ------------------------------------------------------------------ backward
-    def backward(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
-        """Overwrites ``grads`` (same layout as ``params``) with d loss / d params for the last forward."""
+    def backward_steps(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor):
+        """Backward pass as a generator (see forward_steps)."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         dZ = self._work(1, 32)
         if self.perm is not None:
@@ -257,7 +283,7 @@ class GcnEngine:
             if not have_sums:                                    # else: produced by the SpMM that wrote dZ
                 ops.bn_bwd_reduce(dZ, Y, self.bn4[l], sums2=self.sums, n_rows=n)
             have_sums = False
-            comm.all_reduce_sum(self.sums[: 2 * co])
+            yield comm.start_all_reduce(self.sums[: 2 * co])
             ops.bn_bwd_prepare(self.sums, self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % i),
                                L.view(grads, "bn%d.bias" % i), self.c10[:, :co])
             others = [k for k in range(3) if k != cur]
@@ -269,7 +295,7 @@ class GcnEngine:
                 ops.gemm_tn_bnbwd(dZ, Y, self.P[l], self.bn4[l], self.c10[:, :co], out=dW, n_rows=n)
                 dP = self._work(others[0], ci)
                 ops.gemm_nn_bnbwd(dZ, Y, W, self.bn4[l], self.c10[:, :co], out=dP, n_rows=n)
-                comm.halo_exchange(dP, n)
+                yield comm.start_halo(dP, n)
                 dZ = self._work(others[1], ci)
                 have_sums = spmm_to_dz(dP, dZ, l)
                 cur = others[1]
@@ -286,12 +312,12 @@ class GcnEngine:
                 if l > 0:
                     dP = self._work(cur, ci)                    # dZ is dead once dY exists
                     ops.gemm_nn(dY, W, out=dP, n_rows=n)
-                    comm.halo_exchange(dP, n)
+                    yield comm.start_halo(dP, n)
                     dZ = self._work(others[1], ci)
                     have_sums = spmm_to_dz(dP, dZ, l)
                     cur = others[1]
             else:
-                comm.halo_exchange(dY, n)
+                yield comm.start_halo(dY, n)
                 dH = self._work(cur, co)
                 ops.spmm(g, dY, out=dH[:n])
                 ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n)
@@ -299,4 +325,3 @@ class GcnEngine:
                     dZ = self._work(others[1], ci)
                     ops.gemm_nn(dH, W, out=dZ, n_rows=n)
                     cur = others[1]
-        return grads
