@@ -249,6 +249,7 @@ def main():
         if hasattr(tr, "use_graph"):
             tr.use_graph = False             # per-launch events need the eager path
             tr.overlap = False
+            tr.peng.async_wgrad = tr.neng.async_wgrad = False
         for _ in range(args.profile_steps):
             tr.step().item()
         summ = ops.PROF.summary()

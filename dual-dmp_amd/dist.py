@@ -344,6 +344,8 @@ class DistributedTrainer:
         # DDMP_DIST_INTERLEAVE=0: run the two nets one after the other with blocking collectives (A/B, fallback)
         import os
         self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "1") != "0"
+        if torch.device(device).type == "cuda" and os.environ.get("DDMP_ASYNC_WGRAD") == "1":
+            self.peng.async_wgrad = self.neng.async_wgrad = True    # opt-in: weight gradients beside the dgrad chain
 
     def barrier(self):
         self.backend.barrier()

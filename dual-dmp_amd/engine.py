@@ -171,9 +171,11 @@ class GcnEngine:
 
         self.Y = [buf(L.cout[l]) for l in range(12)]                   # conv outputs (pre-BN), saved
         self.P = [buf(L.cin_p[l]) if self.agg_first[l] else None for l in range(12)]
-        self._flat = [torch.empty(nc * cmax, dtype=torch.float32, device=dev) for _ in range(3)]
+        self._flat = [torch.empty(nc * cmax, dtype=torch.float32, device=dev) for _ in range(6)]   # work buffers (rotation)
         self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
-        self.c10 = torch.empty((2, cmax), dtype=torch.float32, device=dev)
+        self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
+        self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
+        self._side = None
         self.sums = torch.empty(2 * cmax, dtype=torch.float64, device=dev)
         self.running = [torch.zeros((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         for r in self.running:
@@ -192,6 +194,11 @@ class GcnEngine:
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
 
     # ------------------------------------------------------------------ forward
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     @staticmethod
     def _drain(steps):
         for h in steps:
@@ -253,16 +260,52 @@ class GcnEngine:
 
     # ------------------------------------------------------------------ backward
     def backward_steps(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor):
-        """Backward pass as a generator (see forward_steps)."""
+        """Backward pass as a generator (see forward_steps).
+
+        ``async_wgrad`` (opt-in, DDMP_ASYNC_WGRAD=1): every weight gradient (a compute-bound GEMM nothing in this pass
+        waits for) is issued on a second stream, after the dgrad GEMM and beside the HBM-bound kernels that follow
+        (SpMM, BatchNorm passes).  In isolation a 512x512 wgrad and SpMM + reduction take 4.1 ms together against
+        3.7 + 1.6 ms one after the other (scripts/overlap_probe.py); inside the pass the gain is 0.4-0.8 ms per
+        iteration at 1M faces, because the wgrad panels leave the SpMM one wave slot per SIMD.  Work buffers read by a
+        wgrad in flight carry its completion event and are only handed out again after the main stream has waited on
+        it (six buffers in rotation: the wait is long over)."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
-        dZ = self._work(1, 32)
+        side = self._side_stream() if self.async_wgrad else None
+        free = list(range(len(self._flat)))                     # FIFO: a buffer guarded by a wgrad is reused last
+        guard = {}
+
+        def take(c):
+            k = free.pop(0)
+            ev = guard.pop(k, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return k, self._work(k, c)
+
+        def release(k):
+            free.append(k)
+
+        def wgrad(fn, *bufs):
+            """fn() launches the weight-gradient GEMM; bufs = work buffers it reads."""
+            if side is None:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+                done = torch.cuda.Event()
+                done.record(side)
+            for k in bufs:
+                guard[k] = done
+
+        kz, dZ = take(32)
         if self.perm is not None:
             dout = dout.index_select(0, self.perm)
         ops.head_bwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
                      L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, dout.contiguous(), dZ,
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
                      L.view(grads, "linear2.weight"), L.view(grads, "linear2.bias"), n_rows=n)
-        cur = 1                                   # index of the work buffer holding dZ
         have_sums = False
         fuse_red = hasattr(ops, "spmm_bnred")
 
@@ -279,49 +322,59 @@ class GcnEngine:
             co, ci = L.cout[l], L.cin_p[l]
             W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
             dW = L.view(grads, "conv%d.lin.weight" % i, true_shape=False)
-            Y = self.Y[l]
+            Y, bn4, c10 = self.Y[l], self.bn4[l], self.c10s[l]
             if not have_sums:                                    # else: produced by the SpMM that wrote dZ
-                ops.bn_bwd_reduce(dZ, Y, self.bn4[l], sums2=self.sums, n_rows=n)
+                ops.bn_bwd_reduce(dZ, Y, bn4, sums2=self.sums, n_rows=n)
             have_sums = False
             yield comm.start_all_reduce(self.sums[: 2 * co])
-            ops.bn_bwd_prepare(self.sums, self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % i),
-                               L.view(grads, "bn%d.bias" % i), self.c10[:, :co])
-            others = [k for k in range(3) if k != cur]
+            ops.bn_bwd_prepare(self.sums, self.n_total, bn4, L.view(grads, "bn%d.weight" % i),
+                               L.view(grads, "bn%d.bias" % i), c10)
             if self.fuse_bnbwd[l]:
                 # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads.
                 # Its column sums (the conv-bias gradient) are exactly zero in exact arithmetic -- BatchNorm's backward
                 # output has zero column mean -- where the reference's autograd leaves float32 summation noise.
                 L.view(grads, "conv%d.bias" % i).zero_()
-                ops.gemm_tn_bnbwd(dZ, Y, self.P[l], self.bn4[l], self.c10[:, :co], out=dW, n_rows=n)
-                dP = self._work(others[0], ci)
-                ops.gemm_nn_bnbwd(dZ, Y, W, self.bn4[l], self.c10[:, :co], out=dP, n_rows=n)
+                kp, dP = take(ci)
+                ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n)
+                # after the dgrad GEMM: two panel GEMMs cannot share a CU (LDS), the wgrad's partners are the SpMM and
+                # the BatchNorm passes that follow
+                wgrad(lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n), kz)
+                release(kz)
                 yield comm.start_halo(dP, n)
-                dZ = self._work(others[1], ci)
+                kz, dZ = take(ci)
                 have_sums = spmm_to_dz(dP, dZ, l)
-                cur = others[1]
+                release(kp)
                 continue
-            dY = self._work(others[0], co)
-            ops.bn_bwd_apply(dZ, Y, self.bn4[l], self.c10[:, :co], dY, self.sums, n_rows=n)
+            ky, dY = take(co)
+            ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, self.sums, n_rows=n)
+            release(kz)                                          # dZ is dead once dY exists
             ops.f64_to_f32(self.sums[:co], L.view(grads, "conv%d.bias" % i))
             if l > 0:
                 Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
             else:
                 Xp, pro = self.x0, None
             if self.agg_first[l]:
-                ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n)
                 if l > 0:
-                    dP = self._work(cur, ci)                    # dZ is dead once dY exists
+                    kp, dP = take(ci)
                     ops.gemm_nn(dY, W, out=dP, n_rows=n)
+                wgrad(lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n), ky)
+                if l > 0:
+                    release(ky)
                     yield comm.start_halo(dP, n)
-                    dZ = self._work(others[1], ci)
+                    kz, dZ = take(ci)
                     have_sums = spmm_to_dz(dP, dZ, l)
-                    cur = others[1]
+                    release(kp)
+                else:
+                    release(ky)
             else:
                 yield comm.start_halo(dY, n)
-                dH = self._work(cur, co)
+                kh, dH = take(co)
                 ops.spmm(g, dY, out=dH[:n])
-                ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n)
+                release(ky)
                 if l > 0:
-                    dZ = self._work(others[1], ci)
+                    kz, dZ = take(ci)
                     ops.gemm_nn(dH, W, out=dZ, n_rows=n)
-                    cur = others[1]
+                wgrad(lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
+                release(kh)
+        if side is not None:                                     # the gradients are complete when this pass returns
+            torch.cuda.current_stream().wait_stream(side)

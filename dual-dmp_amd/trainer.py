@@ -48,6 +48,12 @@ class FusedTrainer:
         self.use_graph = use_graph
         self.overlap = overlap and self.peng.comm.world_size == 1
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        # weight gradients on a further stream beside the dgrad chain: opt-in (DDMP_ASYNC_WGRAD=1), eager mode only.
+        # Measured 0.4-0.8 ms per iteration at 1M faces (the wgrad panels leave one wave slot per SIMD to the SpMM
+        # beside them), and hipStreamEndCapture crashes on the resulting graph topology (events waited on that are
+        # not the tail of their stream).
+        import os
+        self.peng.async_wgrad = self.neng.async_wgrad = (os.environ.get("DDMP_ASYNC_WGRAD") == "1" and not use_graph)
         self._graphs = {}       # gate -> torch.cuda.CUDAGraph
         self._warm = False
         self._t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
