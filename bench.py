@@ -124,7 +124,7 @@ def pmc_traffic(name):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     tot_b = tot_n = 0.0
     for k in d.get("per_kernel", []):
@@ -135,7 +135,7 @@ def pmc_traffic(name):
         if fam == want or (name == "gemm" and fam.startswith("gemm_")):
             tot_b += (k["hbm_read_GB"] + k["hbm_write_GB"]) * 1e9
             tot_n += k["launches"]
-    return {"bytes_per_launch": round(tot_b / tot_n), "source": os.path.basename(files[-1])} if tot_n else None
+    return (round(tot_b / tot_n), os.path.basename(files[-1])) if tot_n else (None, None)
 
 
 def roofline_obj(name, f):
@@ -148,14 +148,17 @@ def roofline_obj(name, f):
             ach, peak, what = f32_eq, MFMA_F32_PEAK_TF, "f32-input MFMA"
         else:
             ach, peak, what = f32_eq * mode, MFMA_BF16_PEAK_TF, "bf16x%d split MFMA: %d bf16 MFMA products per f32 product" % (mode, mode)
+        tb, tsrc = pmc_traffic(name)
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(name),
+                "frac": round(ach / peak, 4), "traffic": tb, "traffic_source": tsrc,
+                "algorithmic_f32_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
                 "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
                 "note": "%s; achieved counts the MFMA flops actually issued; algorithmic f32-equivalent rate = %.1f TFLOP/s "
                         "(= %.2f of the 157.3 TF f32-input-MFMA peak)" % (what, f32_eq, f32_eq / MFMA_F32_PEAK_TF)}
     ach = f["bytes"] / (ms * 1e-3) / 1e9
+    tb, tsrc = pmc_traffic(name)
     return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name),
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tb, "traffic_source": tsrc,
             "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
             "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
 
