@@ -317,17 +317,18 @@ struct TnPlan {
 };
 
 bool tn_panel_enabled();
+int64_t tn_panel_min_rows();
 
 TnPlan tn_plan(int64_t n_rows, int M, int K) {
     TnPlan p;
     p.T = (M >= 128 && K >= 128) ? 2 : 1;
-    if (M >= 256 && K >= 256 && n_rows >= 65536 && tn_panel_enabled()) {
+    if (M >= 256 && K >= 256 && n_rows >= tn_panel_min_rows() && tn_panel_enabled()) {
         p.T = 4;
         p.n_tiles_m = (int)cdiv(M, 256);
         p.n_tiles_k = (int)cdiv(K, 256);
         const int tiles = p.n_tiles_m * p.n_tiles_k;
-        // one 512-thread workgroup per CU; at least 1024 rows per split; multiple of 8 splits (XCD mapping)
-        int64_t s = std::min<int64_t>(std::max<int64_t>(1, kCu / tiles), std::max<int64_t>(1, n_rows / 1024));
+        // one 512-thread workgroup per CU; at least 256 rows (16 stages) per split; multiple of 8 splits (XCD mapping)
+        int64_t s = std::min<int64_t>(std::max<int64_t>(1, kCu / tiles), std::max<int64_t>(1, n_rows / 256));
         s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
         int64_t rps = cdiv(cdiv(n_rows, s), 32) * 32;
         p.rows_per_split = (int)rps;
@@ -357,6 +358,13 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
 }  // namespace
 
 namespace {
+int64_t tn_panel_min_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("DDMP_TN_PANEL_MIN_ROWS");
+        return (e && atoll(e) > 0) ? (int64_t)atoll(e) : (int64_t)30000;
+    }();
+    return v;
+}
 bool tn_panel_enabled() {                                       // DDMP_GEMM_PANEL=0 / DDMP_GEMM_MODE=0: tiled kernels
     const char* v = getenv("DDMP_GEMM_PANEL");
     return !(v && atoi(v) == 0) && ddmp_get_gemm_mode() != 0;
@@ -427,8 +435,15 @@ static bool panel_enabled() {
     return e == 1;
 }
 // Row panels leave CUs idle on small inputs (one 512-thread workgroup per 128/256 rows): measured better from ~25k
-// rows (50k-face mesh 4.74 vs 5.02 ms/iteration, 13k-face mesh 4.08 vs 3.03); the wgrad panels from ~64k rows.
-constexpr int64_t kPanelMinRows = 20000, kTnPanelMinRows = 65536;
+// rows (50k-face mesh 4.74 vs 5.02 ms/iteration, 13k-face mesh 4.08 vs 3.03); the wgrad panels from ~30k rows
+// (62k rows: 512x512 243 vs 291 us, 256x256 90 vs 87 us; row splits as short as 256 rows keep every CU busy).
+static int64_t env_rows(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return (v && atoll(v) > 0) ? atoll(v) : dflt;
+}
+// (DDMP_PANEL_MIN_ROWS / DDMP_TN_PANEL_MIN_ROWS override the thresholds for A/B runs)
+static const int64_t kPanelMinRows = env_rows("DDMP_PANEL_MIN_ROWS", 20000);
+static const int64_t kTnPanelMinRows = env_rows("DDMP_TN_PANEL_MIN_ROWS", 30000);
 static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes,
                             int64_t n_rows) {
     return panel_enabled() && n_rows >= kPanelMinRows && KD % 32 == 0 && KD >= 32 && (KD >= 64 || MD <= 128) &&

@@ -226,7 +226,7 @@ int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t 
  * engine; replaces ddmp_bn_bwd_apply_f32 + ddmp_gemm_nn_f32 + ddmp_gemm_tn_f32 of util/networks.py's autograd chain):
  *     dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0        (a, b, c1, c0 per column, from ddmp_bn_bwd_prepare_f32)
  * ddmp_gemm_bnbwd_supported(cout, cin, n_rows) says whether BOTH fused GEMMs exist for a layer of that shape and row
- * count in the current GEMM mode (the panel kernels they live in are used from ~64k rows); the conv-bias gradient (column sums of dY) is exactly zero in exact arithmetic and is written as 0. */
+ * count in the current GEMM mode (the panel kernels they live in are used from ~30k rows); the conv-bias gradient (column sums of dY) is exactly zero in exact arithmetic and is written as 0. */
 int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows);
 int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,
                            float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b,

@@ -11,6 +11,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle (small meshes) is run by PyTorch-CPU: on a many-core GPU host the all-cores default is tens of
+    # times slower than a handful of threads (measured: 40x on a 256-core box; one suite run took 523 s instead of 84 s)
+    try:
+        import torch
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
+    except Exception:  # pragma: no cover
+        pass
 
 
 @pytest.fixture(scope="session")
