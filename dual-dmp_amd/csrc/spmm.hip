@@ -480,8 +480,9 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 //  lgkmcnt only and keep their Y stores in flight.
 //  Result: SLOWER (3.1 vs 4.4 TB/s on the Morton-ordered face graph).  52 KB of LDS allow 3 workgroups per CU and each
 //  has one slab (13 KB) in flight behind a per-slab barrier: ~40 KB in flight per CU against the slab kernel's 32
-//  waves x 4 KB, i.e. the copy latency is exposed.  Kept for A/B; a version worth shipping needs smaller chunks or a
-//  deeper slab ring than the LDS leaves room for.
+//  waves x 4 KB, i.e. the copy latency is exposed.  A 32-row-chunk version (28 KB of LDS, 5 workgroups per CU) came to
+//  975 us (the slab kernel: 872 us on the same Morton-ordered face graph, 59 % of 8 TB/s), the vertex graph 697 vs 635 us:
+//  the per-slab barrier chain stays latency-bound.  Kept for A/B only.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPMax = 176;          // patch rows (multiple of 8); Morton-ordered meshes: mean 100-120, max ~170
 
