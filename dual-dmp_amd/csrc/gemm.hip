@@ -339,9 +339,10 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
     p.n_tiles_m = (int)cdiv(M, bt);
     p.n_tiles_k = (int)cdiv(K, bt);
     const int tiles = p.n_tiles_m * p.n_tiles_k;
-    // aim at ~3 workgroups per CU; at least 512 rows per split; multiple of 8 splits (XCD mapping)
+    // aim at ~3 workgroups per CU; at least 128 rows per split (small meshes: a split of 512 rows is 32 dependent
+    // stages, 40-50 us per wgrad at 13k rows); multiple of 8 splits (XCD mapping)
     int64_t want = std::max<int64_t>(1, (3 * kCu) / tiles);
-    int64_t max_by_rows = std::max<int64_t>(1, n_rows / 512);
+    int64_t max_by_rows = std::max<int64_t>(1, n_rows / 128);
     int64_t s = std::min(want, max_by_rows);
     s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
     int64_t rps = cdiv(n_rows, s);
