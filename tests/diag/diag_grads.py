@@ -1,7 +1,7 @@
 """Diagnostic: per-parameter gradient error of the HIP engine vs the float64 oracle, with selectable
 perturbations of the (initially trivial) conv biases / BN affine parameters."""
 import sys, os, copy
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as ge
 oracle = ge._load_oracle()

@@ -1,6 +1,6 @@
 """Diagnostic: how far do free-running trajectories drift?  HIP-f32 vs oracle-f32 vs oracle-f64."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as ge
 oracle = ge._load_oracle()

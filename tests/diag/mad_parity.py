@@ -3,7 +3,7 @@
 weights, on small synthetic meshes.  Adam makes the trajectories chaotic (they separate ~10x per iteration), so the
 comparison is between END RESULTS: the oracle's own float32-vs-float64 gap is the yardstick."""
 import importlib.util, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import types
 import numpy as np, torch

@@ -1,5 +1,6 @@
+"""Free-running MAD / loss statistics over several seeds: HIP path vs the float32 CPU oracle (test infrastructure)."""
 import importlib.util, os, sys, types
-ROOT="/root/repo"; sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 torch.set_num_threads(8)
 spec = importlib.util.spec_from_file_location("ddmp_oracle", os.path.join(ROOT, "oracle", "ddmp_oracle.py"))
