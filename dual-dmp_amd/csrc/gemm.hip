@@ -456,7 +456,7 @@ template <int PM>
 static void launch_panel(int mode, const float* A, int64_t lda, const float* A2, int64_t lda2, const float* W,
                          int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
                          const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
-                         float slope, hipStream_t st, float* stats = nullptr, double* sums = nullptr) {
+                         float slope, hipStream_t st, double* stats = nullptr, double* sums = nullptr) {
     // wide outputs: 128 x 512 | 256 x 256 blocks (64 x 128 per wave); narrow outputs (MD <= 128): 512-row blocks, 64 x 32 NJ
     const int WC = MD > 256 ? 4 : MD > 128 ? 2 : 1, WR = 8 / WC;
     const int NJ = MD > 128 ? 4 : MD > 64 ? 4 : MD > 32 ? 2 : 1;
@@ -490,7 +490,7 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
     }
 #undef DDMP_PANEL
     if (stats && sums) {
-        const size_t pbytes = ((size_t)n_row_tiles * WR * 2 * MP * sizeof(float) + 255) / 256 * 256;
+        const size_t pbytes = ((size_t)n_row_tiles * WR * 2 * MP * sizeof(double) + 255) / 256 * 256;
         fpartials_reduce(stats, n_row_tiles * WR, MP, MD, (double*)((char*)stats + pbytes), sums, st);
     }
 }
@@ -798,7 +798,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
 //      fused into the row-panel kernel's epilogue where that kernel runs, otherwise GEMM + ddmp_bn_stats_f32
 extern "C" size_t ddmp_gemm_nt_stats_workspace_bytes(int64_t n_rows, int M) {
     if (n_rows <= 0 || M <= 0) return 0;
-    const size_t fused = (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(float) + 256 + fpartials_mid_bytes(512);
+    const size_t fused = (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(double) + 256 + fpartials_mid_bytes(512);
     return std::max(fused, ddmp_colreduce_workspace_bytes(n_rows, M));
 }
 
@@ -815,8 +815,8 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
                        panel_ok(K, M, Y, ldy, workspace, workspace_bytes, n_rows);
     if (fused) {
         hipStream_t st = (hipStream_t)stream;
-        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (float*)stats_ws, sums2);
-        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, (float*)stats_ws, sums2);
+        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (double*)stats_ws, sums2);
+        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, (double*)stats_ws, sums2);
         LAUNCH_TRY();
         return DDMP_OK;
     }

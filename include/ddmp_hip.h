@@ -213,7 +213,7 @@ int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float*
 
 /* ddmp_gemm_nt_f32 that also returns the BatchNorm statistics of its output (float64 [2M]: column sums of Y and of
  * Y^2 over the n_rows rows = what ddmp_bn_stats_f32(Y) returns; GCNConv -> BatchNorm1d, util/networks.py:52-53).  The
- * row-panel kernel produces them in its epilogue (float32 partials per 64 rows, summed in float64); other shapes run
+ * row-panel kernel produces them in its epilogue (float64 partials per 64 rows); other shapes run
  * the GEMM followed by ddmp_bn_stats_f32. */
 size_t ddmp_gemm_nt_stats_workspace_bytes(int64_t n_rows, int M);
 int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,

@@ -200,6 +200,13 @@ def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
     yd = y.double().cpu()
     assert relerr(sums[:M], yd.sum(0)) < 1e-6
     assert relerr(sums[M:], (yd * yd).sum(0)) < 1e-6
+    # a column mean 1e3 times the spread (mean^2 / var = 1e6: float32 partial sums would be off by ~10 %): the variance is a difference of the two sums, which must therefore be (nearly)
+    # exact sums of the stored float32 values -- float64 partials in the epilogue, as in the separate pass
+    y = ops.gemm_nt_stats(a.to(dev), (w * 0.1).to(dev), sums, bias=(bias * 0 + 100.0).to(dev))
+    yd = y.double().cpu()
+    var_ref = yd.var(0, unbiased=False)
+    var = sums[M:].cpu() / n - (sums[:M].cpu() / n) ** 2
+    assert float(((var - var_ref).abs() / var_ref).max()) < 1e-6
 
 
 def test_gemm_transpose_detecting(dev, gemm_mode):
