@@ -714,8 +714,8 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
 #define DDMP_TN_BY_MODE(T_, PRO_)                                                 \
     do {                                                                          \
         const int mode_ = gemm_mode();                                            \
-        if (mode_ == 6) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 3, PRO_>));       \
-        else if (mode_ == 3) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 2, PRO_>));  \
+        if (mode_ == 6) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 3, PRO_, (T_ == 1 ? 32 : 16)>));       \
+        else if (mode_ == 3) DDMP_LAUNCH_TN((gemm_tn_bf16_kernel<T_, 2, PRO_, (T_ == 1 ? 32 : 16)>));  \
         else DDMP_LAUNCH_TN((gemm_tn_kernel<T_, PRO_>));                          \
     } while (0)
     if (p.T == 2) {
