@@ -180,6 +180,12 @@ def main():
     ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table (JSON) here")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything else this process or the libraries under it
+    # write to fd 1 (the RCCL version banner, for one) goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -307,7 +313,8 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
             with open(args.kernel_table, "w") as fh:
                 json.dump({"config": line["config"], "ms_per_step": line["ms_per_step"], "kernels": table}, fh, indent=1)
-        print(json.dumps(line))
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    os.close(result_fd)
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
