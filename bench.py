@@ -146,6 +146,12 @@ def roofline_obj(name, f):
         f32_eq = f["flops"] / (ms * 1e-3) / 1e12          # algorithmic (f32) FLOP/s
         if mode == 0:
             ach, peak, what = f32_eq, MFMA_F32_PEAK_TF, "f32-input MFMA"
+        elif mode == 13:
+            nprod = 3
+            ach, peak, what = f32_eq * nprod, MFMA_BF16_PEAK_TF, (
+                "f16x%d split MFMA in the row-panel kernels: %d f16 MFMA products per f32 product (f16 and bf16 MFMA share the "
+                "2.5 PF peak); the narrow layers' kernels stay bf16x6, their 6 products are counted as %d: a lower bound"
+                % (nprod, nprod, nprod))
         else:
             ach, peak, what = f32_eq * mode, MFMA_BF16_PEAK_TF, "bf16x%d split MFMA: %d bf16 MFMA products per f32 product" % (mode, mode)
         tb, tsrc = pmc_traffic(name)
@@ -229,6 +235,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    tr.check_scales()                    # f16 split GEMM modes: no operand was clamped (raises otherwise)
     if world > 1 or force_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -299,7 +306,9 @@ def main():
             "value": round(args.steps / elapsed, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": {6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA"}[ops.get_gemm_mode()],
+            "gemm_arithmetic": {6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA",
+                                13: "f16x3 split MFMA on scaled operands, f32 accumulate (f32-class accuracy; bf16x6 in the narrow layers)",
+                                }[ops.get_gemm_mode()],
             "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, float32, k=(3,4,4,4,1), "
                                    "bnfloop=%d, %s numbering (BASELINE.json configs[2])" % (F, V, args.bnfloop, args.order),
                        "faces": F, "verts": V, "parallelism": "1 GPU" if world == 1 else "%d-way face/vertex partition + 1-hop halo" % world,

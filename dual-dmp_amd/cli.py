@@ -80,6 +80,7 @@ def run(argv=None, real: bool = False):
         if epoch % 10 == 0 or epoch == args.iter:
             print("Epoch {}: loss={:.6f}".format(epoch, loss) + ("" if mad_value is None else " mad={:.3f}".format(mad_value)))
         if epoch % 10 == 0:
+            tr.check_scales()
             if ev is not None:
                 mad_value = ev.mad(tr.pos)
             if real or epoch % 100 == 0:

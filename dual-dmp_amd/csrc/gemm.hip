@@ -452,29 +452,82 @@ static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const v
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
 }
+// f16 split mode (gemm_f16s.inc): 0 | 13; operand scale slots of the NEXT ddmp_gemm_* call on this host thread
+static int gemm_f16();
+struct ScaleCtx {
+    float* a = nullptr;
+    float* b = nullptr;
+    int prime = 0;
+};
+static thread_local ScaleCtx g_scale_ctx;
+static ScaleCtx take_scale_ctx() {
+    ScaleCtx c = g_scale_ctx;
+    g_scale_ctx = ScaleCtx();
+    return c;
+}
+// slot[0] = max |f(A)|, exactly (pre-pass)
+template <int PM>
+static void f16s_measure(const float* A, int64_t lda, const float* A2, int64_t lda2, int64_t n_rows, int C,
+                         const float* pa, const float* pb, const float* pk1, const float* pk0, float slope, float* slot,
+                         hipStream_t st) {
+    (void)hipMemsetAsync(slot, 0, 16, st);
+    const int64_t total = n_rows * (C / 4);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256 * 8), 8 * device_cus());
+    hipLaunchKernelGGL((f16s_absmax_kernel<PM>), dim3((unsigned)std::max(grid, 1)), dim3(256), 0, st, A, lda, A2, lda2,
+                       n_rows, C, pa, pb, pk1, pk0, slope, slot);
+}
+
 template <int PM>
 static void launch_panel(int mode, const float* A, int64_t lda, const float* A2, int64_t lda2, const float* W,
                          int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
                          const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
-                         float slope, hipStream_t st, double* stats = nullptr, double* sums = nullptr) {
+                         float slope, hipStream_t st, double* stats = nullptr, double* sums = nullptr,
+                         ScaleCtx ctx = ScaleCtx()) {
     // wide outputs: 128 x 512 | 256 x 256 blocks (64 x 128 per wave); narrow outputs (MD <= 128): 512-row blocks, 64 x 32 NJ
     const int WC = MD > 256 ? 4 : MD > 128 ? 2 : 1, WR = 8 / WC;
     const int NJ = MD > 128 ? 4 : MD > 64 ? 4 : MD > 32 ? 2 : 1;
     const int MP = 32 * NJ * WC, BMR = 64 * WR;
     const int n_row_tiles = (int)ddmp::cdiv(n_rows, BMR);
-    {
-        const int64_t total = (int64_t)MP * KD;
-        const int sgrid = (int)std::min<int64_t>(ddmp::cdiv(total, 256), 1024);
-        if (mode == 6)
-            hipLaunchKernelGGL((split_w_panel_kernel<3>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes);
-        else
-            hipLaunchKernelGGL((split_w_panel_kernel<2>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes);
-    }
+    const int64_t total = (int64_t)MP * KD;
+    const int sgrid = (int)std::min<int64_t>(ddmp::cdiv(total, 256), 1024);
     dim3 grid((unsigned)std::min(n_row_tiles, device_cus())), block(512);
-    const __bf16* Bp = (const __bf16*)planes;
+    const int f16 = (mode == 6 && WC > 1 && lda % 4 == 0 && (PM != 2 || lda2 % 4 == 0)) ? gemm_f16() : 0;
+    if (f16) {
+        // two f16 planes of W * wscale; the scale and (without caller slots) the A operand's slot sit behind them
+        char* tail = (char*)planes + (size_t)2 * MP * KD * 2;
+        float* wscale = (float*)tail;
+        float* slot = ctx.a ? ctx.a : (float*)(tail + 16);
+        const bool prime = !ctx.a || ctx.prime;
+        hipLaunchKernelGGL(f16s_wscale_kernel, dim3(1), dim3(1024), 0, st, W, ldw, transpose ? KD : MD, transpose ? MD : KD, wscale);
+        hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
+                           (_Float16*)planes, (const float*)wscale);
+        if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
+        const int target = prime ? kF16TargetExact : kF16TargetStale;
+        const void* Bh = planes;
+#define DDMP_PANEL_H(WR_, WC_, AR_)                                                                               \
+    hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, AR_, PM, 4>), grid, block, 0, st, A, lda, A2, lda2, Bh, Y, ldy,   \
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, slot, (const float*)wscale, target)
+        if (WC == 4) {
+            DDMP_PANEL_H(2, 4, 13);
+        } else {
+            DDMP_PANEL_H(4, 2, 13);
+        }
+#undef DDMP_PANEL_H
+        if (stats && sums) {
+            const size_t pbytes = ((size_t)n_row_tiles * WR * 2 * MP * sizeof(double) + 255) / 256 * 256;
+            fpartials_reduce(stats, n_row_tiles * WR, MP, MD, (double*)((char*)stats + pbytes), sums, st);
+        }
+        return;
+    }
+    if (mode == 6)
+        hipLaunchKernelGGL((split_w_panel_kernel<3, __bf16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((split_w_panel_kernel<2, __bf16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes, (const float*)nullptr);
+    const void* Bp = planes;
 #define DDMP_PANEL(WR_, WC_, NT_, NJ_)                                                                            \
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM, NJ_>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy, \
-                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats)
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, (float*)nullptr,            \
+                       (const float*)nullptr, 0)
     if (WC == 4) {
         if (mode == 6) DDMP_PANEL(2, 4, 3, 4); else DDMP_PANEL(2, 4, 2, 4);
     } else if (WC == 2) {
@@ -501,22 +554,42 @@ static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void
            ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD);
 }
 
-// GEMM arithmetic: 6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA
-static int g_gemm_mode = -1;
+// GEMM arithmetic: 6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA;
+// 13 = f16x3 in the row-panel kernels (gemm_f16s.inc), bf16x6 everywhere else
+static int g_gemm_mode = -1, g_gemm_f16 = 0;
 static int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("DDMP_GEMM_MODE");
         int m = e ? atoi(e) : 6;
+        g_gemm_f16 = m == 13 ? m : 0;
         g_gemm_mode = (m == 0 || m == 3 || m == 6) ? m : 6;
     }
     return g_gemm_mode;
 }
+static int gemm_f16() {
+    (void)gemm_mode();
+    return g_gemm_f16;
+}
 extern "C" int ddmp_set_gemm_mode(int mode) {
-    if (mode != 0 && mode != 3 && mode != 6) return DDMP_EINVAL;
-    g_gemm_mode = mode;
+    if (mode != 0 && mode != 3 && mode != 6 && mode != 13) return DDMP_EINVAL;
+    g_gemm_f16 = mode > 10 ? mode : 0;
+    g_gemm_mode = mode > 10 ? 6 : mode;
     return DDMP_OK;
 }
-extern "C" int ddmp_get_gemm_mode(void) { return gemm_mode(); }
+extern "C" int ddmp_get_gemm_mode(void) { return gemm_f16() ? gemm_f16() : gemm_mode(); }
+
+extern "C" int ddmp_gemm_next_scales(float* slot_a, float* slot_b, int prime) {
+    g_scale_ctx.a = slot_a;
+    g_scale_ctx.b = slot_b;
+    g_scale_ctx.prime = prime;
+    return DDMP_OK;
+}
+extern "C" int ddmp_gemm_scales_roll(float* slots, int n_slots, ddmp_stream stream) {
+    ARG_TRY(slots && n_slots > 0);
+    hipLaunchKernelGGL(f16s_roll_kernel, dim3((unsigned)cdiv(n_slots, 64)), dim3(64), 0, (hipStream_t)stream, slots, n_slots);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -546,6 +619,7 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
                                 int64_t ldy, int64_t n_rows, int K, int M, const float* bias,
                                 const float* pro_scale, const float* pro_shift, float slope,
                                 void* workspace, size_t workspace_bytes, ddmp_stream stream) {
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
     ARG_TRY(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K && ldy >= M);
     ARG_TRY(aligned16(A) && aligned16(W));
@@ -557,8 +631,8 @@ extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     const int n_col_tiles = (int)cdiv(M, 64 * TN);
     dim3 grid((unsigned)(cdiv(n_row_tiles, kXcd) * kXcd * n_col_tiles)), block(256);
     if (gemm_mode() != 0 && !(pro_scale && K > 512) && panel_ok(K, M, Y, ldy, workspace, workspace_bytes, n_rows)) {
-        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st);
-        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st);
+        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, nullptr, nullptr, ctx);
+        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, nullptr, nullptr, ctx);
         LAUNCH_TRY();
         return DDMP_OK;
     }
@@ -605,6 +679,7 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
                                 int64_t ldy, int64_t n_rows, int M, int K, void* workspace,
                                 size_t workspace_bytes, ddmp_stream stream) {
     // Y[n,K] = A[n,M] . W[M,K] : reduction over M, output width K
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(A && W && Y && n_rows > 0 && K > 0 && M > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ldy >= K);
     ARG_TRY(aligned16(A) && aligned16(W));
@@ -616,7 +691,7 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     // pre-split W^T: planes [K_out][M] so that the reduction index M is contiguous; the rows kernel then runs
     // in its row-major (NT) form on the planes
     if (gemm_mode() != 0 && panel_ok(M, K, Y, ldy, workspace, workspace_bytes, n_rows)) {
-        launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, st);
+        launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 1, workspace, Y, ldy, (int)n_rows, M, K, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, st, nullptr, nullptr, ctx);
         LAUNCH_TRY();
         return DDMP_OK;
     }
@@ -668,13 +743,14 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
 extern "C" size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K) {
     if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
     TnPlan p = tn_plan(n_rows, M, K);
-    return (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    return (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;    // + two scale slots (f16 modes)
 }
 
 extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW,
                                 int64_t lddw, int64_t n_rows, int M, int K, const float* pro_scale,
                                 const float* pro_shift, float slope, void* workspace,
                                 size_t workspace_bytes, ddmp_stream stream) {
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(G && Z && dW && n_rows > 0 && M > 0 && K > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && ldg >= M && ldz >= K && lddw >= K);
     ARG_TRY(aligned16(G) && aligned16(Z));
@@ -682,20 +758,40 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     ARG_TRY(!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
     hipStream_t st = (hipStream_t)stream;
     TnPlan p = tn_plan(n_rows, M, K);
-    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;
     if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
     float* part = (float*)workspace;
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
     if (p.T == 4) {
         dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
+        float* gslot = nullptr;
+        float* zslot = nullptr;
+        int target = 0;
 #define DDMP_LAUNCH_TNP(KERNEL_)                                                                              \
     hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, G, ldg, (const float*)nullptr, (int64_t)0, Z, ldz, part, \
                        (int64_t)K, sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k,       \
                        p.n_splits, pro_scale, pro_shift, (const float*)nullptr, (const float*)nullptr,           \
-                       (const float*)nullptr, (const float*)nullptr, slope)
+                       (const float*)nullptr, (const float*)nullptr, slope, gslot, zslot, target)
         const int mode_ = gemm_mode();
-        if (pro_scale) {
+        if (mode_ == 6 && gemm_f16()) {
+            float* tail = (float*)((char*)workspace + need - 64);
+            const bool own = !(ctx.a && ctx.b);
+            gslot = own ? tail : ctx.a;
+            zslot = own ? tail + 4 : ctx.b;
+            const bool prime = own || ctx.prime;
+            target = prime ? kF16TargetExact : kF16TargetStale;
+            if (prime) {
+                f16s_measure<0>(G, ldg, nullptr, 0, n_rows, M, nullptr, nullptr, nullptr, nullptr, slope, gslot, st);
+                if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
+                else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
+            }
+            if (pro_scale) {
+                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, false>));
+            } else {
+                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, false>));
+            }
+        } else if (pro_scale) {
             if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, false>));
         } else {
             if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false, false>));
@@ -746,12 +842,13 @@ extern "C" int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float
                                       const float* a, const float* b, const float* c1, const float* c0, float slope,
                                       void* workspace, size_t workspace_bytes, ddmp_stream stream) {
     // out[n,K] = dY[n,M] . W[M,K],  dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0  (per column of M)
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(dZ && Yb && W && out && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
     ARG_TRY(lddz % 4 == 0 && ldyb % 4 == 0 && ldw % 4 == 0 && lddz >= M && ldyb >= M && ldw >= K && ld_out >= K);
     ARG_TRY(aligned16(dZ) && aligned16(Yb) && aligned16(W));
     if (!ddmp_gemm_bnbwd_supported(M, K, n_rows) || !panel_ok(M, K, out, ld_out, workspace, workspace_bytes, n_rows)) return DDMP_EINVAL;
     launch_panel<2>(gemm_mode(), dZ, lddz, Yb, ldyb, W, ldw, 1, workspace, out, ld_out, (int)n_rows, M, K, nullptr, a, b,
-                    c1, c0, slope, (hipStream_t)stream);
+                    c1, c0, slope, (hipStream_t)stream, nullptr, nullptr, ctx);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -762,6 +859,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
                                       const float* pro_scale, const float* pro_shift, float slope, void* workspace,
                                       size_t workspace_bytes, ddmp_stream stream) {
     // dW[M,K] = dY^T . f(Z),  dY as above (columns of M), f = optional BatchNorm+LeakyReLU prologue on Z (columns of K)
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(dZ && Yb && Z && dW && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lddz >= M && ldyb >= M && ldz >= K && lddw >= K);
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
@@ -769,18 +867,38 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     hipStream_t st = (hipStream_t)stream;
     TnPlan p = tn_plan(n_rows, M, K);
     if (p.T != 4) return DDMP_EINVAL;
-    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;
     if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
     float* part = (float*)workspace;
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
     dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
+    float* gslot = nullptr;
+    float* zslot = nullptr;
+    int target = 0;
 #define DDMP_LAUNCH_TNP(KERNEL_)                                                                                 \
     hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, dZ, lddz, Yb, ldyb, Z, ldz, part, (int64_t)K, sstride,     \
                        (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale,       \
-                       pro_shift, a, b, c1, c0, slope)
+                       pro_shift, a, b, c1, c0, slope, gslot, zslot, target)
     const int mode_ = gemm_mode();
-    if (pro_scale) {
+    if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0) {
+        float* tail = (float*)((char*)workspace + need - 64);
+        const bool own = !(ctx.a && ctx.b);
+        gslot = own ? tail : ctx.a;
+        zslot = own ? tail + 4 : ctx.b;
+        const bool prime = own || ctx.prime;
+        target = prime ? kF16TargetExact : kF16TargetStale;
+        if (prime) {
+            f16s_measure<2>(dZ, lddz, Yb, ldyb, n_rows, M, a, b, c1, c0, slope, gslot, st);
+            if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
+            else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
+        }
+        if (pro_scale) {
+            DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, true>));
+        } else {
+            DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, true>));
+        }
+    } else if (pro_scale) {
         if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, true>));
     } else {
         if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, false, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, false, true>));
@@ -807,6 +925,7 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
                                       const float* pro_shift, float slope, double* sums2, void* workspace,
                                       size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
                                       ddmp_stream stream) {
+    const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(sums2 && stats_ws);
     if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, M)) return DDMP_EWORKSPACE;
     const bool fused = A && W && Y && n_rows > 0 && n_rows < INT32_MAX && K > 0 && M > 0 && K % 4 == 0 && lda % 4 == 0 &&
@@ -815,11 +934,12 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
                        panel_ok(K, M, Y, ldy, workspace, workspace_bytes, n_rows);
     if (fused) {
         hipStream_t st = (hipStream_t)stream;
-        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (double*)stats_ws, sums2);
-        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, (double*)stats_ws, sums2);
+        if (pro_scale) launch_panel<1>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr, slope, st, (double*)stats_ws, sums2, ctx);
+        else launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 0, workspace, Y, ldy, (int)n_rows, K, M, bias, nullptr, nullptr, nullptr, nullptr, slope, st, (double*)stats_ws, sums2, ctx);
         LAUNCH_TRY();
         return DDMP_OK;
     }
+    g_scale_ctx = ctx;
     int rc = ddmp_gemm_nt_f32(A, lda, W, ldw, Y, ldy, n_rows, K, M, bias, pro_scale, pro_shift, slope, workspace,
                               workspace_bytes, stream);
     if (rc != DDMP_OK) return rc;

@@ -353,6 +353,10 @@ class DistributedTrainer:
     def gather_pos(self):
         return self.full[: self.sd.V]
 
+    def check_scales(self):
+        self.peng.check_scales()
+        self.neng.check_scales()
+
     @torch.no_grad()
     def step(self):
         o = self.ops

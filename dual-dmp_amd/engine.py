@@ -175,6 +175,13 @@ class GcnEngine:
         self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
+        # f16 split GEMM modes: one scale slot per layer and GEMM operand (0: the forward operand X, 1: the gradient
+        # operand); the kernels record the operand maxima of this iteration, backward() rolls them into the scales
+        # of the next one.  The first iteration measures (prime).
+        self.scale_slots = torch.zeros((12, 2, 4), dtype=torch.float32, device=dev)
+        self._slot = [[self.scale_slots[l, o] for o in range(2)] for l in range(12)]
+        self._prime = True
+        self._f16 = False
         self._side = None
         self.sums = torch.empty(2 * cmax, dtype=torch.float64, device=dev)
         self.running = [torch.zeros((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
@@ -192,6 +199,21 @@ class GcnEngine:
 
     def _work(self, i, c):
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
+
+    def _scales(self, l, a, b=None):
+        """Name the operand scale slots of the next GEMM call (f16 split modes only)."""
+        if self._f16:
+            ops.gemm_next_scales(self._slot[l][a], None if b is None else self._slot[l][b], self._prime)
+
+    def check_scales(self):
+        """f16 split modes: raise if an operand outgrew its scale (values were clamped) since the last check.  Syncs."""
+        flags = self.scale_slots[:, :, 2].view(torch.int32)
+        if bool(flags.any().item()):
+            where = [(int(l), int(o)) for l, o in flags.nonzero().tolist()]
+            flags.zero_()
+            self._prime = True                                   # measure again on the next (eager) iteration
+            raise OverflowError("GEMM operand exceeded its f16 scale (layer, operand): %s -- values were clamped in the "
+                                "last iterations; re-run them (DDMP_GEMM_MODE=6 avoids scaled operands)" % where)
 
     # ------------------------------------------------------------------ forward
     def _side_stream(self):
@@ -220,6 +242,7 @@ class GcnEngine:
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
         (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        self._f16 = hasattr(ops, "gemm_next_scales") and ops.get_gemm_mode() == 13
         X, pro = self.x0, None
         for l in range(12):
             i = l + 1
@@ -233,6 +256,7 @@ class GcnEngine:
                         yield comm.start_halo(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
                     self._p1_ready = True
+                self._scales(l, 0)
                 if hasattr(ops, "gemm_nt_stats"):                # BatchNorm statistics from the GEMM epilogue
                     ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n)
                 else:
@@ -240,6 +264,7 @@ class GcnEngine:
                     ops.bn_stats(Y, sums=self.sums, n_rows=n)
             else:
                 H = self._work(0, L.cout[l])
+                self._scales(l, 0)
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n)
                 yield comm.start_halo(H, n)
                 ops.spmm(g, H, out=Y[:n], bias=b)
@@ -284,15 +309,17 @@ class GcnEngine:
         def release(k):
             free.append(k)
 
-        def wgrad(fn, *bufs):
-            """fn() launches the weight-gradient GEMM; bufs = work buffers it reads."""
+        def wgrad(l, fn, *bufs):
+            """fn() launches the weight-gradient GEMM of layer l; bufs = work buffers it reads."""
             if side is None:
+                self._scales(l, 1, 0)
                 fn()
                 return
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             side.wait_event(ev)
             with torch.cuda.stream(side):
+                self._scales(l, 1, 0)
                 fn()
                 done = torch.cuda.Event()
                 done.record(side)
@@ -335,10 +362,11 @@ class GcnEngine:
                 # output has zero column mean -- where the reference's autograd leaves float32 summation noise.
                 L.view(grads, "conv%d.bias" % i).zero_()
                 kp, dP = take(ci)
+                self._scales(l, 1)
                 ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n)
                 # after the dgrad GEMM: two panel GEMMs cannot share a CU (LDS), the wgrad's partners are the SpMM and
                 # the BatchNorm passes that follow
-                wgrad(lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n), kz)
+                wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n), kz)
                 release(kz)
                 yield comm.start_halo(dP, n)
                 kz, dZ = take(ci)
@@ -356,8 +384,9 @@ class GcnEngine:
             if self.agg_first[l]:
                 if l > 0:
                     kp, dP = take(ci)
+                    self._scales(l, 1)
                     ops.gemm_nn(dY, W, out=dP, n_rows=n)
-                wgrad(lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n), ky)
+                wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n), ky)
                 if l > 0:
                     release(ky)
                     yield comm.start_halo(dP, n)
@@ -373,8 +402,12 @@ class GcnEngine:
                 release(ky)
                 if l > 0:
                     kz, dZ = take(ci)
+                    self._scales(l, 1)
                     ops.gemm_nn(dH, W, out=dZ, n_rows=n)
-                wgrad(lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
+                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
                 release(kh)
         if side is not None:                                     # the gradients are complete when this pass returns
             torch.cuda.current_stream().wait_stream(side)
+        if self._f16:
+            ops.gemm_scales_roll(self.scale_slots)
+            self._prime = False

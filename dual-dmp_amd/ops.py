@@ -72,12 +72,27 @@ def _p(t):
 
 
 def set_gemm_mode(mode: int):
-    """6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA."""
+    """6 = bf16x6 split MFMA (f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA; 13 = f16x3 split MFMA
+    in the row-panel kernels (f32-class accuracy, scaled operands: see gemm_next_scales), bf16x6 elsewhere."""
     check(_lib.lib().ddmp_set_gemm_mode(int(mode)), "ddmp_set_gemm_mode")
 
 
 def get_gemm_mode() -> int:
     return int(_lib.lib().ddmp_get_gemm_mode())
+
+
+def gemm_next_scales(slot_a, slot_b=None, prime=False):
+    """f16 split modes: name the scale slots (float32 [4] device tensors, persistent) of the operands of the NEXT gemm_*
+    call -- slot_a: the row operand (a / dz / g), slot_b: z of the tn forms.  Without this the library measures every
+    operand's absolute maximum in a pre-pass; with it the kernels use the maximum the previous iteration's kernels
+    recorded (gemm_scales_roll), ``prime`` forces the measurement (first iteration)."""
+    check(_lib.lib().ddmp_gemm_next_scales(_p(slot_a), _p(slot_b), int(bool(prime))), "ddmp_gemm_next_scales")
+
+
+def gemm_scales_roll(slots):
+    """Once per iteration: the maxima recorded by this iteration's GEMM kernels become the next iteration's scales."""
+    assert slots.dtype == torch.float32 and slots.is_contiguous() and slots.shape[-1] == 4
+    check(_lib.lib().ddmp_gemm_scales_roll(_p(slots), slots.numel() // 4, _stream()), "ddmp_gemm_scales_roll")
 
 
 def _chk(t, dtype=torch.float32, name="tensor"):

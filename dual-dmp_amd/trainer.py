@@ -118,6 +118,11 @@ class FusedTrainer:
         return lossbuf, pos, norm
 
     @torch.no_grad()
+    def check_scales(self):
+        """f16 split GEMM modes: raise OverflowError if an operand outgrew its scale since the last check (syncs)."""
+        self.peng.check_scales()
+        self.neng.check_scales()
+
     def step(self):
         self.epoch += 1
         self.t += 1

@@ -111,10 +111,11 @@ def test_spmm_multi_edges_and_self_loops(dev):
     assert relerr(y, dense_ahat(keep, n) @ x.double()) < 1e-6
 
 
-@pytest.fixture(params=[6, 3, 0], ids=["bf16x6", "bf16x3", "f32mfma"])
+@pytest.fixture(params=[6, 3, 0, 13], ids=["bf16x6", "bf16x3", "f32mfma", "f16x3"])
 def gemm_mode(request):
-    """Every GEMM arithmetic of the library: the default bf16x6 split MFMA (f32-class accuracy), bf16x3
-    (three products, ~2^-16 per product) and the f32-input MFMA kernels."""
+    """Every GEMM arithmetic of the library: the bf16x6 split MFMA (f32-class accuracy), bf16x3 (three products,
+    ~2^-16 per product), the f32-input MFMA kernels, and f16x3 (scaled operands, two f16 terms, three products:
+    f32-class accuracy) in the row-panel kernels with bf16x6 elsewhere."""
     from dual_dmp_amd import ops
     old = ops.get_gemm_mode()
     ops.set_gemm_mode(request.param)
@@ -122,7 +123,7 @@ def gemm_mode(request):
     ops.set_gemm_mode(old)
 
 
-GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6}
+GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6, 13: 2e-6}
 
 
 @pytest.mark.parametrize("n,K,M", [(1000, 32, 64), (777, 512, 512), (130, 8, 32), (513, 256, 128),
@@ -207,6 +208,73 @@ def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
     var_ref = yd.var(0, unbiased=False)
     var = sums[M:].cpu() / n - (sums[:M].cpu() / n) ** 2
     assert float(((var - var_ref).abs() / var_ref).max()) < 1e-6
+
+
+@pytest.fixture
+def f16x3():
+    from dual_dmp_amd import ops
+    old = ops.get_gemm_mode()
+    ops.set_gemm_mode(13)
+    yield
+    ops.set_gemm_mode(old)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-20, 1e20, 1e-30])
+def test_f16x3_operand_scaling(dev, f16x3, scale):
+    """f16 has 5 exponent bits: the f16x3 kernels scale every operand by a power of two derived from its absolute
+    maximum (measured in a pre-pass when the caller names no scale slots).  Operands of any float32 magnitude, with
+    columns and rows spread over many orders of magnitude, come out at float32-class accuracy (norm-wise)."""
+    from dual_dmp_amd import ops
+    n, K, M = 40000, 256, 512
+    torch.manual_seed(5)
+    a = torch.randn(n, K) * scale
+    a[:, : K // 4] *= 1e-3                                          # quiet columns
+    a[: n // 2] *= 0.02                                             # quiet rows
+    w = torch.randn(M, K) / K ** 0.5
+    g0 = torch.randn(n, M) * 1e-4 * torch.rand(n, 1) ** 4           # gradient-like: few loud rows
+    g, gt = g0 * scale, g0 / scale                                  # (the wgrad's product stays in float32 range)
+    ag, wg, gg, gtg = a.to(dev), w.to(dev), g.to(dev), gt.to(dev)
+    assert relerr(ops.gemm_nt(ag, wg), a.double() @ w.double().t()) < 2e-6
+    assert relerr(ops.gemm_nn(gg, wg), g.double() @ w.double()) < 2e-6
+    assert relerr(ops.gemm_tn(gtg, ag), gt.double().t() @ a.double()) < 3e-6
+    z = torch.zeros(n, K, device=dev)                               # all-zero operand: scale 1, exact zeros
+    assert float(ops.gemm_nt(z, wg).abs().max()) == 0.0
+
+
+def test_f16x3_scale_slots(dev, f16x3):
+    """The training-loop protocol: persistent slots, primed once, then each call uses the maximum recorded by the
+    previous iteration's kernels (ddmp_gemm_scales_roll).  Growth within the head-room (x 64) is exact business as
+    usual; growth beyond it is clamped and raises the slot's flag."""
+    from dual_dmp_amd import ops
+    n, K, M = 40000, 256, 256
+    torch.manual_seed(6)
+    a, w, g = torch.randn(n, K), torch.randn(M, K) / K ** 0.5, torch.randn(n, M) * 1e-3
+    ag, wg, gg = a.to(dev), w.to(dev), g.to(dev)
+    slots = torch.zeros(2, 4, device=dev)
+    ref = a.double() @ w.double().t()
+    ops.gemm_next_scales(slots[0], None, prime=True)
+    assert relerr(ops.gemm_nt(ag, wg), ref) < 2e-6
+    amax = float(a.abs().max())
+    assert float(slots[0, 0]) == amax and float(slots[0, 1]) == amax          # measured, and seen by the kernel
+    ops.gemm_scales_roll(slots)
+    assert float(slots[0, 0]) == amax and float(slots[0, 1]) == 0.0
+    for grow in (1.0, 30.0, 0.01):                                  # stale scale, data moved: still float32-class
+        ops.gemm_next_scales(slots[0], None)
+        assert relerr(ops.gemm_nt(ag * grow, wg), ref * grow) < 2e-6
+        assert int(slots[0, 2].view(torch.int32)) == 0
+        assert float(slots[0, 1]) == float((a * grow).abs().max())
+        slots[0, 1] = 0.0
+    # both operands of the wgrad form
+    ops.gemm_next_scales(slots[1], slots[0], prime=True)
+    assert relerr(ops.gemm_tn(gg, ag), g.double().t() @ a.double()) < 3e-6
+    ops.gemm_scales_roll(slots)
+    ops.gemm_next_scales(slots[1], slots[0])
+    assert relerr(ops.gemm_tn(gg * 5, ag), 5 * (g.double().t() @ a.double())) < 3e-6
+    assert int(slots[:, 2].view(torch.int32).abs().sum()) == 0
+    # beyond the head-room: flagged (and clamped, so the result is off)
+    ops.gemm_next_scales(slots[0], None)
+    ops.gemm_nt(ag * 1000.0, wg)
+    assert int(slots[0, 2].view(torch.int32)) == 1
 
 
 def test_gemm_transpose_detecting(dev, gemm_mode):
