@@ -155,12 +155,20 @@ def roofline_obj(name, f):
         else:
             ach, peak, what = f32_eq * mode, MFMA_BF16_PEAK_TF, "bf16x%d split MFMA: %d bf16 MFMA products per f32 product" % (mode, mode)
         tb, tsrc = pmc_traffic(name)
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": tb, "traffic_source": tsrc,
-                "algorithmic_f32_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
-                "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
-                "note": "%s; achieved counts the MFMA flops actually issued; algorithmic f32-equivalent rate = %.1f TFLOP/s "
-                        "(= %.2f of the 157.3 TF f32-input-MFMA peak)" % (what, f32_eq, f32_eq / MFMA_F32_PEAK_TF)}
+        note = ("%s; the MFMA figures count the MFMA flops actually issued; algorithmic f32-equivalent rate = %.1f TFLOP/s "
+                "(= %.2f of the 157.3 TF f32-input-MFMA peak)" % (what, f32_eq, f32_eq / MFMA_F32_PEAK_TF))
+        mfma = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+        gbs = f["bytes"] / (ms * 1e-3) / 1e9                # algorithmic bytes: operands read once, result written once
+        hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        # the roofline that binds is the one with the larger lower bound on the time (= the larger fraction)
+        first, other = (hbm, mfma) if hbm["frac"] > mfma["frac"] else (mfma, hbm)
+        out = {"kernel": name}
+        out.update(first)
+        out.update({"traffic": tb, "traffic_source": tsrc, "other_roofline": other,
+                    "algorithmic_f32_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
+                    "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
+                    "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1)), "note": note})
+        return out
     ach = f["bytes"] / (ms * 1e-3) / 1e9
     tb, tsrc = pmc_traffic(name)
     return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

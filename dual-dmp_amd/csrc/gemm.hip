@@ -498,7 +498,9 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         float* wscale = (float*)tail;
         float* slot = ctx.a ? ctx.a : (float*)(tail + 16);
         const bool prime = !ctx.a || ctx.prime;
-        hipLaunchKernelGGL(f16s_wscale_kernel, dim3(1), dim3(1024), 0, st, W, ldw, transpose ? KD : MD, transpose ? MD : KD, wscale);
+        (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
+        hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
+                           transpose ? KD : MD, transpose ? MD : KD, wscale);
         hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
                            (_Float16*)planes, (const float*)wscale);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
@@ -554,13 +556,13 @@ static inline bool ws_ok(int KD, int MD, const float* Y, int64_t ldy, const void
            ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD);
 }
 
-// GEMM arithmetic: 6 = bf16x6 split MFMA (default, f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA;
-// 13 = f16x3 in the row-panel kernels (gemm_f16s.inc), bf16x6 everywhere else
+// GEMM arithmetic: 13 (default) = f16x3 split MFMA in the row-panel kernels (gemm_f16s.inc), bf16x6 everywhere else;
+// 6 = bf16x6 split MFMA everywhere; both f32-class accuracy.  3 = bf16x3 (~2^-16), 0 = f32-input MFMA
 static int g_gemm_mode = -1, g_gemm_f16 = 0;
 static int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("DDMP_GEMM_MODE");
-        int m = e ? atoi(e) : 6;
+        int m = e ? atoi(e) : 13;
         g_gemm_f16 = m == 13 ? m : 0;
         g_gemm_mode = (m == 0 || m == 3 || m == 6) ? m : 6;
     }

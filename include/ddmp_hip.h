@@ -94,21 +94,22 @@ int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, f
                      int64_t n_rows, int M, int K, void* workspace /*nullable*/, size_t workspace_bytes,
                      ddmp_stream stream);
 size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
-/* GEMM arithmetic: 6 = bf16x6 split MFMA (default: every f32 operand is split into three bf16 terms, six
- * bf16 MFMA products accumulated in f32 -- f32-class accuracy at 2.67x the f32-MFMA rate), 3 = bf16x3
- * (three products, ~2^-16 relative), 0 = f32-input MFMA (v_mfma_f32_32x32x2_f32).  Process-wide; the
- * environment variable DDMP_GEMM_MODE sets the initial value. */
+/* GEMM arithmetic (process-wide; the environment variable DDMP_GEMM_MODE sets the initial value):
+ *   6  = bf16x6 split MFMA: every f32 operand is split into three bf16 terms, six bf16 MFMA products accumulated in
+ *        f32 -- f32-class accuracy at 2.67x the f32-MFMA rate;
+ *   13 = (default) f16x3 in the row-panel kernels (the wide layers of big meshes), bf16x6 everywhere else: the
+ *        operand, scaled by a power of two, is split into two _Float16 terms (22-23 bits) and three f16 MFMA products
+ *        are accumulated in f32 (the "3xTF32" scheme; csrc/gemm_f16s.inc) -- f32-class accuracy, half the MFMA work;
+ *   3  = bf16x3 (three products, ~2^-16 relative);   0 = f32-input MFMA (v_mfma_f32_32x32x2_f32).
+ * Mode 13's power of two comes from the operand's absolute maximum, kept in a "scale slot" (device float[4]: {maximum
+ * in use, maximum seen by the last kernels, overflow flag, -}).  By default the library measures it in a pre-pass over
+ * the operand.  A training loop avoids that pass: ddmp_gemm_next_scales names persistent slots for the NEXT ddmp_gemm_*
+ * call of this host thread (slot_a: the row operand A / dZ / G; slot_b: Z of the tn forms; prime != 0: measure now
+ * anyway, e.g. first iteration), the GEMM kernels record the maximum they see, and ddmp_gemm_scales_roll, once per
+ * iteration, makes it the next iteration's scale (6 bits of head-room; anything that still overflows is clamped to the
+ * f16 range and raises the slot's flag). */
 int ddmp_set_gemm_mode(int mode);
 int ddmp_get_gemm_mode(void);
-/* Mode 13 = f16x3 in the row-panel kernels (the wide layers of big meshes; bf16x6 everywhere else): the
- * operand, scaled by a power of two, is split into two _Float16 terms (22-23 bits) and three f16 MFMA products
- * are accumulated in f32 (the "3xTF32" scheme; csrc/gemm_f16s.inc).  The power of two comes from the operand's
- * absolute maximum, kept in a "scale slot" (device float[4]: {maximum in use, maximum seen by the last kernels,
- * overflow flag, -}).  By default the library measures it in a pre-pass over the operand.  A training loop avoids that
- * pass: ddmp_gemm_next_scales names persistent slots for the NEXT ddmp_gemm_* call of this host thread (slot_a: the row
- * operand A / dZ / G; slot_b: Z of the tn forms; prime != 0: measure now anyway, e.g. first iteration), the GEMM
- * kernels record the maximum they see, and ddmp_gemm_scales_roll, once per iteration, makes it the next iteration's
- * scale (6 bits of head-room; anything that still overflows is clamped to the f16 range and raises the slot's flag). */
 int ddmp_gemm_next_scales(float* slot_a, float* slot_b, int prime);
 int ddmp_gemm_scales_roll(float* slots, int n_slots, ddmp_stream stream);
 int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW, int64_t lddw,
