@@ -104,7 +104,7 @@ struct BwdApplyF {
         o.y = fmaf(a.y, dz.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope), fmaf(k1.y, y.y, k0.y));
         o.z = fmaf(a.z, dz.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope), fmaf(k1.z, y.z, k0.z));
         o.w = fmaf(a.w, dz.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope), fmaf(k1.w, y.w, k0.w));
-        *reinterpret_cast<float4*>(dY + (int64_t)row * lddy + cc) = o;
+        nt_store4(dY + (int64_t)row * lddy + cc, o);
         s0[0] += o.x; s0[1] += o.y; s0[2] += o.z; s0[3] += o.w;
         (void)s1;
     }

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void spmm_patch_kernel(
         o.y = fmaf(acc.y, di, bs.y);
         o.z = fmaf(acc.z, di, bs.z);
         o.w = fmaf(acc.w, di, bs.w);
-        *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + c0 + sl * 4) = o;
+        nt_store4(Y + (int64_t)row * ldy + c0 + sl * 4, o);
     }
 }
 
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                         o.y = fmaf(acc[q][s].y, di, bs[s].y);
                         o.z = fmaf(acc[q][s].z, di, bs[s].z);
                         o.w = fmaf(acc[q][s].w, di, bs[s].w);
-                        *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + off + s * CS) = o;
+                        nt_store4(Y + (int64_t)row * ldy + off + s * CS, o);
                         if (RED) {
                             const float4 y = *reinterpret_cast<const float4*>(red.Yp + (int64_t)row * red.ldyp + off);
                             const float g0 = o.x * lrelu_grad(fmaf(y.x, ra.x, rb.x), slope);
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(320) void spmm_patch_dma_kernel(
             o.y = fmaf(acc.y, di, bs.y);
             o.z = fmaf(acc.z, di, bs.z);
             o.w = fmaf(acc.w, di, bs.w);
-            *reinterpret_cast<float4*>(Y + (int64_t)row * ldy + off) = o;
+            nt_store4(Y + (int64_t)row * ldy + off, o);
             if (RED) {
                 const float4 y = *reinterpret_cast<const float4*>(red.Yp + (int64_t)row * red.ldyp + off);
                 const float g0 = o.x * lrelu_grad(fmaf(y.x, ra.x, rb.x), slope);
