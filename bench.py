@@ -243,7 +243,11 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    tr.check_scales()                    # f16 split GEMM modes: no operand was clamped (raises otherwise)
+    scale_overflow = None                # f16x3 GEMM mode: did an operand outgrow its scale (values clamped)?
+    try:
+        tr.check_scales()
+    except OverflowError as e:
+        scale_overflow = str(e)
     if world > 1 or force_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -324,6 +328,7 @@ def main():
                        "two_streams": bool(args.overlap) and world == 1 and not force_dist},
             "loss": round(float(loss), 6),
             "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
+            "gemm_scale_overflow": scale_overflow,
         }
         line.update(out)
         if args.kernel_table:
