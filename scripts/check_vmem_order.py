@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Static check of the row-panel GEMM kernels' ISA: panel_barrier(NL) waits with s_waitcnt vmcnt(NL), which is only
-correct if the NL youngest VMEM instructions before it are the register loads of A -- every global_load_lds (the W
-copies, which the barrier must cover) has to be OLDER.  The scheduler is free to reorder independent VMEM instructions,
-so this is checked on the generated code.  usage: check_vmem_order.py [gemm.s]  (compiles csrc/gemm.hip if omitted)"""
+"""Static check of the row-panel GEMM kernels' ISA: panel_barrier(n) waits with s_waitcnt vmcnt(n), which is only
+correct if the n youngest VMEM instructions before it are the ones that may still be in flight: with two stage buffers
+the register loads of A -- every global_load_lds (the W copies the barrier must cover) has to be OLDER; with three
+(f16 modes) everything issued since the previous barrier, and nothing older.  The scheduler is free to reorder
+independent VMEM instructions, so this is checked on the generated code (linear scan: loop bodies are unrolled).  usage: check_vmem_order.py [gemm.s]  (compiles csrc/gemm.hip if omitted)"""
 import os, re, subprocess, sys, tempfile
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,25 +22,34 @@ while i < len(lines):
         i += 1
         continue
     name = m.group(1)
-    recent = []                  # VMEM instructions since the last wait / barrier, oldest first
+    three = re.search(r"gemm_panel_kernelILi\d+ELi\d+ELi1[34]E", name) is not None      # f16 modes: three stage buffers
+    recent = []                  # VMEM instructions not yet known complete, oldest first: (kind, barrier segment)
+    seg = 0
     i += 1
     while i < len(lines) and not lines[i].strip().startswith("s_endpgm"):
         t = lines[i].strip()
         if t.startswith("global_load_lds"):
-            recent.append("lds")
+            recent.append(("lds", seg))
         elif t.startswith("global_load") or t.startswith("buffer_load"):
-            recent.append("reg")
+            recent.append(("reg", seg))
         elif t.startswith("global_store") or t.startswith("global_atomic"):
-            recent.append("st")
+            recent.append(("st", seg))
         w = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
         if w:
             n = int(w.group(1))
-            n_checked += 1
-            young = recent[len(recent) - n:] if n else []
-            if "lds" in young:
-                bad += 1
-                print("HAZARD %s: vmcnt(%d) leaves a global_load_lds in flight (stream tail: %s)" % (name[:90], n, recent[-8:]))
             recent = recent[len(recent) - n:] if n else []
+            at_barrier = any(lines[j].strip().startswith("s_barrier") for j in range(i + 1, min(i + 3, len(lines))))
+            if at_barrier:
+                n_checked += 1
+                # two buffers: no W copy may be in flight at the barrier.  three: only copies issued since the
+                # previous barrier (they have one more stage to land).
+                late = [k for k, sg in recent if k == "lds" and (not three or sg < seg)]
+                if late:
+                    bad += 1
+                    print("HAZARD %s: vmcnt(%d) before s_barrier leaves %d stale global_load_lds in flight (tail: %s)"
+                          % (name[:90], n, len(late), recent[-8:]))
+        if t.startswith("s_barrier"):
+            seg += 1
         i += 1
-print("checked %d vmcnt waits in gemm_panel_kernel instances: %d hazards" % (n_checked, bad))
+print("checked %d barrier waits in gemm_panel_kernel instances: %d hazards" % (n_checked, bad))
 sys.exit(1 if bad else 0)
