@@ -59,6 +59,18 @@ class NoComm:
         return None
 
 
+class _Both:
+    """Two started collectives as one handle."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def wait(self):
+        for h in (self.a, self.b):
+            if h is not None:
+                h.wait()
+
+
 class ArenaLayout:
     """Offsets (in floats) of every parameter tensor inside the flat arena."""
 
@@ -244,6 +256,7 @@ class GcnEngine:
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         self._f16 = hasattr(ops, "gemm_next_scales") and ops.get_gemm_mode() == 13
         X, pro = self.x0, None
+        halo_started = False
         for l in range(12):
             i = l + 1
             W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
@@ -252,7 +265,7 @@ class GcnEngine:
             if self.agg_first[l]:
                 P = self.P[l]
                 if l > 0 or not self._p1_ready:
-                    if l > 0:
+                    if l > 0 and not halo_started:
                         yield comm.start_halo(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
                     self._p1_ready = True
@@ -269,7 +282,12 @@ class GcnEngine:
                 yield comm.start_halo(H, n)
                 ops.spmm(g, H, out=Y[:n], bias=b)
                 ops.bn_stats(Y, sums=self.sums, n_rows=n)
-            yield comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
+            # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
+            # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
+            h_stats = comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
+            halo_started = l < 11 and self.agg_first[l + 1]
+            h_halo = comm.start_halo(Y, n) if halo_started else None
+            yield _Both(h_stats, h_halo)
             ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
                            self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
             X, pro = Y, (self.bn4[l][0], self.bn4[l][1])
