@@ -152,7 +152,8 @@ def test_training_iteration_invariances_at_1m(big):
 def test_fused_engine_matches_unfused_kernels_at_140k():
     """Above 64k rows the engine takes its fused routes (BatchNorm statistics from the GEMM epilogue, BatchNorm backward
     rebuilt on the dgrad/wgrad operand loads, backward reductions from the SpMM epilogue, row-panel GEMMs).  GEMM mode 0
-    (f32-input MFMA kernels) has none of the panel kernels, so the same step through both modes checks the fused
+    (f32-input MFMA kernels) has none of the panel kernels, so the same step through the modes (bf16x6, f16x3 panels on
+    scaled operands, f32 MFMA) checks the split arithmetic and the fused
     bookkeeping (buffer rotation, which sums belong to which layer) end to end: outputs and every gradient agree to
     float32 GEMM rounding."""
     from dual_dmp_amd import ops, synth
@@ -169,7 +170,7 @@ def test_fused_engine_matches_unfused_kernels_at_140k():
     old = ops.get_gemm_mode()
     res = {}
     try:
-        for mode in (6, 0):
+        for mode in (13, 6, 0):
             ops.set_gemm_mode(mode)
             torch.manual_seed(3)
             out = []
@@ -182,7 +183,7 @@ def test_fused_engine_matches_unfused_kernels_at_140k():
                         elif name.endswith("bias"):
                             view.normal_(std=0.1)
                 eng = net._get_engine(data)
-                if mode == 6:
+                if mode != 0:
                     assert any(eng.fuse_bnbwd), "the fused BatchNorm-backward route must be active at this size"
                 o = eng.forward(net.arena.data, update_running=False)
                 torch.manual_seed(17)
@@ -193,9 +194,10 @@ def test_fused_engine_matches_unfused_kernels_at_140k():
             res[mode] = out
     finally:
         ops.set_gemm_mode(old)
-    for (o6, g6), (o0, g0) in zip(res[6], res[0]):
-        assert rel(o6, o0) < 2e-5
-        for k in g6:
-            if k.startswith("conv") and k.endswith(".bias"):
-                continue                              # analytically zero (fused route: exactly 0; unfused: rounding noise)
-            assert rel(g6[k], g0[k]) < 5e-3, (k, rel(g6[k], g0[k]))
+    for mode in (6, 13):                              # bf16x6 everywhere | f16x3 row panels (scaled operands) + bf16x6
+        for (o6, g6), (o0, g0) in zip(res[mode], res[0]):
+            assert rel(o6, o0) < 2e-5
+            for k in g6:
+                if k.startswith("conv") and k.endswith(".bias"):
+                    continue                          # analytically zero (fused route: exactly 0; unfused: rounding noise)
+                assert rel(g6[k], g0[k]) < 5e-3, (mode, k, rel(g6[k], g0[k]))
