@@ -309,12 +309,22 @@ struct BnRed {
     float* part;
 };
 
-template <int LANES, int U, int NR, bool PRO, int SL, bool RED = false>
+// BWD: the gathered operand is the BatchNorm+LeakyReLU BACKWARD of (X = dZ, bwd.Yb = the layer's pre-BatchNorm output),
+//     dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0   (a, b = pscale, pshift; element for element BwdApplyF of bn.hip),
+// rebuilt on the gather instead of being written by bn_bwd_apply and read back (GEMM-first layers).
+struct BnBwdGather {
+    const float* Yb;
+    int64_t ldyb;
+    const float *c1, *c0;
+};
+
+template <int LANES, int U, int NR, bool PRO, int SL, bool RED = false, bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_slab_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int chunks_per_xcd, int n_chunks, BnRed red = BnRed()) {
+    float slope, int chunks_per_xcd, int n_chunks, BnRed red = BnRed(), BnBwdGather bwd = BnBwdGather()) {
+    static_assert(!BWD || (PRO && SL == 1 && !RED), "BWD: coefficients a, b come as the prologue's, one slab per pass");
     constexpr int CS = LANES * 4;
     constexpr int RPW = 64 / LANES;
     constexpr int RPB = 4 * RPW;
@@ -364,7 +374,13 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
             }
             bs[s] = bias ? *reinterpret_cast<const float4*>(bias + off + s * CS) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k0 = k1;
+        if (BWD) {
+            k1 = *reinterpret_cast<const float4*>(bwd.c1 + off);
+            k0 = *reinterpret_cast<const float4*>(bwd.c0 + off);
+        }
         const float* xc = X + off;
+        const float* yc = BWD ? bwd.Yb + off : nullptr;
         for (int lr0 = wave * RPW + grp; lr0 < nr; lr0 += RPB * NR) {
             int es[NR], ee[NR];
             float4 acc[NR][SL];
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                         }
                         if (es[q] + k >= ee[q]) wj[q][k] = 0.f;
                     }
-                float4 v[NR][U][SL];
+                float4 v[NR][U][SL], vy[BWD ? NR : 1][BWD ? U : 1];
 #pragma unroll
                 for (int q = 0; q < NR; ++q)
 #pragma unroll
@@ -403,6 +419,7 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                         const float* xr = xc + (int64_t)cj[q][k] * ldx;
 #pragma unroll
                         for (int s = 0; s < SL; ++s) v[q][k][s] = *reinterpret_cast<const float4*>(xr + s * CS);
+                        if (BWD) vy[BWD ? q : 0][BWD ? k : 0] = *reinterpret_cast<const float4*>(yc + (int64_t)cj[q][k] * bwd.ldyb);
                     }
                 more = 0;
 #pragma unroll
@@ -412,7 +429,13 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 #pragma unroll
                         for (int s = 0; s < SL; ++s) {
                             float4 t = v[q][k][s];
-                            if (PRO) t = f4_affine_lrelu(t, pa[s], pb[s], slope);
+                            if (BWD) {
+                                const float4 y = vy[BWD ? q : 0][BWD ? k : 0], a = pa[s], b = pb[s];
+                                t.x = fmaf(a.x, t.x * lrelu_grad(fmaf(y.x, a.x, b.x), slope), fmaf(k1.x, y.x, k0.x));
+                                t.y = fmaf(a.y, t.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope), fmaf(k1.y, y.y, k0.y));
+                                t.z = fmaf(a.z, t.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope), fmaf(k1.z, y.z, k0.z));
+                                t.w = fmaf(a.w, t.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope), fmaf(k1.w, y.w, k0.w));
+                            } else if (PRO) t = f4_affine_lrelu(t, pa[s], pb[s], slope);
                             acc[q][s].x = fmaf(wj[q][k], t.x, acc[q][s].x);
                             acc[q][s].y = fmaf(wj[q][k], t.y, acc[q][s].y);
                             acc[q][s].z = fmaf(wj[q][k], t.z, acc[q][s].z);
@@ -807,6 +830,29 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
     LAUNCH_TRY();
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+// out = A_hat . dY with dY = BatchNorm+LeakyReLU backward of (dZ, Yb) rebuilt on the gather (see BnBwdGather)
+extern "C" int ddmp_spmm_bnbwd_supported(int C) { return (C % 32 == 0 && C >= 32) ? 1 : 0; }
+
+extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb,
+                                   float* out, int64_t ld_out, int C, const float* a, const float* b, const float* c1,
+                                   const float* c0, float slope, ddmp_stream stream) {
+    ARG_TRY(g && dZ && Yb && out && a && b && c1 && c0 && C > 0 && lddz >= C && ldyb >= C && ld_out >= C);
+    ARG_TRY(dZ != out && Yb != out);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!ddmp_spmm_bnbwd_supported(C) || lddz % 4 || ldyb % 4 || ld_out % 4 || !al16(dZ) || !al16(Yb) || !al16(out) ||
+        !al16(a) || !al16(b) || !al16(c1) || !al16(c0))
+        return DDMP_EINVAL;
+    const int n = (int)g->n_rows;
+    const int n_chunks = (int)cdiv(n, kRB);
+    const int cpx = (int)cdiv(n_chunks, kXcd);
+    BnBwdGather bwd{Yb, ldyb, c1, c0};
+    hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
+                       (hipStream_t)stream, g->rowptr, g->col, g->dinv, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,
+                       a, b, slope, cpx, n_chunks, BnRed(), bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -27,6 +27,8 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -175,6 +177,12 @@ class GcnEngine:
         supported = getattr(ops, "gemm_bnbwd_supported", None)
         self.fuse_bnbwd = [bool(supported) and l > 0 and self.agg_first[l] and supported(L.cout[l], L.cin_p[l], self.n_rows)
                            for l in range(12)]
+        # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
+        # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
+        gather_ok = getattr(ops, "spmm_bnbwd_supported", None)
+        self.fuse_gather_bwd = [bool(gather_ok) and isinstance(self.comm, NoComm) and not self.agg_first[l] and l > 0
+                                and gather_ok(L.cout[l]) and os.environ.get("DDMP_SPMM_BNBWD", "1") != "0"
+                                for l in range(12)]
         cmax = max(L.cout)
         nc = self.n_cols
 
@@ -390,6 +398,19 @@ class GcnEngine:
                 kz, dZ = take(ci)
                 have_sums = spmm_to_dz(dP, dZ, l)
                 release(kp)
+                continue
+            if self.fuse_gather_bwd[l]:
+                # transform-first layer on one device: dY is rebuilt by the SpMM on its gather of (dZ, Y) rows
+                L.view(grads, "conv%d.bias" % i).zero_()        # (exactly zero, as in the fused GEMM form above)
+                kh, dH = take(co)
+                ops.spmm_bnbwd(g, dZ, Y, bn4, c10, dH[:n])
+                release(kz)
+                Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
+                kz, dZ = take(ci)
+                self._scales(l, 1)
+                ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
+                release(kh)
                 continue
             ky, dY = take(co)
             ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, self.sums, n_rows=n)

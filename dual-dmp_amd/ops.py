@@ -244,6 +244,25 @@ def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
     return out
 
 
+def spmm_bnbwd_supported(C):
+    return bool(_lib.lib().ddmp_spmm_bnbwd_supported(int(C)))
+
+
+def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
+    """out[:n_rows] = A_hat @ dY with dY = BatchNorm+LeakyReLU backward of (dz, yb) rebuilt on the gather (what
+    bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
+    dz, lddz = _mat(dz, "dz")
+    yb, ldyb = _mat(yb, "yb")
+    out, ldo = _mat(out, "out")
+    C = dz.shape[1]
+    assert dz.shape[0] >= g.n_cols and yb.shape[0] >= g.n_cols and out.shape[0] >= g.n_rows and yb.shape[1] == C
+    with _timed("spmm", C, 4.0 * (2 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows, 2.0 * g.nnz * C):
+        st = _lib.lib().ddmp_spmm_bnbwd_f32(g.handle, _p(dz), lddz, _p(yb), ldyb, _p(out), ldo, C, _p(bn4[0]), _p(bn4[1]),
+                                            _p(c10[0]), _p(c10[1]), slope, _stream())
+    check(st, "ddmp_spmm_bnbwd_f32")
+    return out
+
+
 def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
     a, lda = _mat(a, "a")

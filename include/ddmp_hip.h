@@ -222,6 +222,15 @@ int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float*
                         const float* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
                         const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace,
                         size_t workspace_bytes, ddmp_stream stream);
+/* backward of GCNConv.propagate of a transform-first layer, with the backward of the BatchNorm1d+LeakyReLU behind it
+ * (util/networks.py:51-62 under autograd) rebuilt on the gather: out = A_hat . dY,
+ * dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0 per column (what ddmp_bn_bwd_apply_f32 would have written and this
+ * kernel read back).  C % 32 == 0 (ddmp_spmm_bnbwd_supported). */
+int ddmp_spmm_bnbwd_supported(int C);
+int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb,
+                        float* out, int64_t ld_out, int C, const float* a, const float* b, const float* c1,
+                        const float* c0, float slope, ddmp_stream stream);
+
 
 /* ddmp_gemm_nt_f32 that also returns the BatchNorm statistics of its output (float64 [2M]: column sums of Y and of
  * Y^2 over the n_rows rows = what ddmp_bn_stats_f32(Y) returns; GCNConv -> BatchNorm1d, util/networks.py:52-53).  The

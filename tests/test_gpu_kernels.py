@@ -101,6 +101,30 @@ def test_spmm_with_bn_backward_reduce(dev, graphs, C):
         assert relerr(sums, ref_s) < 1e-5, (gname, relerr(sums, ref_s))
 
 
+@pytest.mark.parametrize("C", [32, 256, 64])
+def test_spmm_with_bn_backward_on_the_gather(dev, graphs, C):
+    """A_hat . dY with dY = BatchNorm+LeakyReLU backward of (dZ, Y) rebuilt on the gather == bn_bwd_apply followed by
+    the plain SpMM, bit for bit (same per-element arithmetic, same accumulation order), and == the float64 formula."""
+    from dual_dmp_amd import ops
+    ei, n = graphs["grid_f"]
+    g = ops.graph_for(ei.to(dev), n)
+    torch.manual_seed(C)
+    dz, yb = torch.randn(n, C, device=dev), torch.randn(n, C, device=dev) * 2 + 0.5
+    bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5]).to(dev)
+    c10 = torch.stack([torch.randn(C) * 0.1, torch.randn(C) * 0.1]).to(dev)
+    assert ops.spmm_bnbwd_supported(C)
+    out = torch.empty(n, C, device=dev)
+    ops.spmm_bnbwd(g, dz, yb, bn4, c10, out)
+    dy = torch.empty_like(dz)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    ops.bn_bwd_apply(dz, yb, bn4, c10, dy, sums)
+    assert torch.equal(out, ops.spmm(g, dy))
+    a, b, k1, k0 = (t.double().cpu() for t in (bn4[0], bn4[1], c10[0], c10[1]))
+    z = yb.double().cpu() * a + b
+    dy_ref = a * dz.double().cpu() * torch.where(z > 0, 1.0, 0.01) + k1 * yb.double().cpu() + k0
+    assert relerr(out, dense_ahat(ei, n) @ dy_ref) < 1e-6
+
+
 def test_spmm_multi_edges_and_self_loops(dev):
     from dual_dmp_amd import ops
     ei = torch.tensor([[0, 1, 1, 2, 2, 0, 1, 3, 3], [1, 0, 2, 1, 0, 2, 0, 3, 3]])
