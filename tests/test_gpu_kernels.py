@@ -237,6 +237,8 @@ def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
 @pytest.fixture
 def f16x3():
     from dual_dmp_amd import ops
+    if os.environ.get("DDMP_GEMM_PANEL") == "0":
+        pytest.skip("f16x3 lives in the row-panel kernels, which are disabled")
     old = ops.get_gemm_mode()
     ops.set_gemm_mode(13)
     yield
