@@ -341,9 +341,11 @@ class DistributedTrainer:
         self.epoch = 0
         self.t = 0
         self.lossbuf = None
-        # DDMP_DIST_INTERLEAVE=0: run the two nets one after the other with blocking collectives (A/B, fallback)
+        # DDMP_DIST_INTERLEAVE=1: the two nets alternate at their collectives (async_op=True).  Off by default: that
+        # path has only run at world size 1 on RCCL and through gloo on CPU (no multi-GPU box in the build loop);
+        # the default is the blocking form, which the threaded-rank GPU tests exercise kernel for kernel.
         import os
-        self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "1") != "0"
+        self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "0") == "1"
         if torch.device(device).type == "cuda" and os.environ.get("DDMP_ASYNC_WGRAD") == "1":
             self.peng.async_wgrad = self.neng.async_wgrad = True    # opt-in: weight gradients beside the dgrad chain
 
@@ -359,6 +361,10 @@ class DistributedTrainer:
 
     @torch.no_grad()
     def step(self):
+        with self.ops.on_device(self.device):
+            return self._step()
+
+    def _step(self):
         o = self.ops
         self.epoch += 1
         self.t += 1

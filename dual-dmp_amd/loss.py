@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ops import _p, _stream
+from .ops import _p, _stream, on_device
 
 _P = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S5": 4, "SIG": 5}
 
@@ -76,14 +76,39 @@ class MeshTables:
         self.device = device
 
 
+def _fingerprint(mesh):
+    """Cheap content version of the connectivity: sizes, buffer addresses and a strided sample of faces / f2f / edges.
+    Catches a replaced or (almost always) an edited array without hashing 24 MB per call at 1M faces; an in-place
+    edit that the sample misses needs :func:`invalidate`."""
+    parts = [len(mesh.vs)]
+    for name in ("faces", "f2f", "edges"):
+        a = np.asarray(getattr(mesh, name))
+        flat = a.reshape(-1)
+        step = max(1, flat.size // 257)
+        parts += [a.shape, a.__array_interface__["data"][0], int(flat[::step].astype(np.int64).sum())]
+    return tuple(parts)
+
+
 def tables_for(mesh, device) -> MeshTables:
+    """Device tables of ``mesh``, cached on the mesh object per device and re-built when its connectivity fingerprint
+    changes (see :func:`_fingerprint`)."""
     cache = mesh.__dict__.setdefault("_ddmp_tables", {})
     key = str(device)
-    t = cache.get(key)
-    if t is None or t.F != len(mesh.faces) or t.V != len(mesh.vs):
-        t = MeshTables(mesh, device)
-        cache[key] = t
-    return t
+    fp = _fingerprint(mesh)
+    hit = cache.get(key)
+    if hit is None or hit[0] != fp:
+        hit = (fp, MeshTables(mesh, device))
+        cache[key] = hit
+    return hit[1]
+
+
+def invalidate(mesh=None):
+    """Drop the cached device copies (connectivity tables of ``mesh``, float64 targets of every mesh): call after
+    editing ``mesh.faces`` / ``f2f`` / ``edges`` / ``vs`` / ``fn`` IN PLACE.  Replacing an array by a new one is
+    detected without this."""
+    if mesh is not None:
+        mesh.__dict__.pop("_ddmp_tables", None)
+    _f64_cache.clear()
 
 
 _f64_cache = {}
@@ -94,7 +119,9 @@ def _target(arr, device):
     if isinstance(arr, torch.Tensor):
         return arr.to(device=device, dtype=torch.float64).contiguous()
     a = np.asarray(arr)
-    key = (a.__array_interface__["data"][0], a.shape, str(a.dtype), str(device))
+    flat = a.reshape(-1)
+    sample = float(flat[::max(1, flat.size // 257)].sum()) if flat.size else 0.0     # in-place edits: see invalidate()
+    key = (a.__array_interface__["data"][0], a.shape, str(a.dtype), str(device), sample)
     hit = _f64_cache.get(key)
     if hit is not None and hit[0] is arr:
         return hit[1]
@@ -109,6 +136,18 @@ def _f32(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.DdmpError("%s must be a CUDA tensor (HIP path, no CPU fallback)" % name)
     return t.detach().to(torch.float32).contiguous()
+
+
+def _pred(t, name):
+    """The reference accepts Union[Tensor, ndarray] predictions (util/loss.py:16-19,55-59); on this path a prediction
+    has to live on the GPU already -- say so instead of failing on ``.device``."""
+    if isinstance(t, np.ndarray) or (isinstance(t, torch.Tensor) and not t.is_cuda):
+        raise _lib.DdmpError("%s: got a %s; the HIP losses take CUDA (ROCm) tensors only -- move it with "
+                             "torch.as_tensor(x).to(device); there is no CPU fallback"
+                             % (name, "numpy array" if isinstance(t, np.ndarray) else "CPU tensor"))
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    return t
 
 
 class _Scratch:
@@ -214,8 +253,9 @@ class _NoAdj:
 def pos_rec_loss(pred_pos, real_pos, ltype="rmse"):
     """reconstruction error for vertex positions (util/loss.py:16-35)."""
     _ltype(ltype, "rmse", ("l1mae", "rmse"))
-    real = _target(real_pos, pred_pos.device)
-    return _PosRec.apply(pred_pos, real, _NoAdj(pred_pos.shape[0], pred_pos.device))
+    with on_device(_pred(pred_pos, "pred_pos")):
+        real = _target(real_pos, pred_pos.device)
+        return _PosRec.apply(pred_pos, real, _NoAdj(pred_pos.shape[0], pred_pos.device))
 
 
 class _Lap(torch.autograd.Function):
@@ -242,8 +282,9 @@ class _Lap(torch.autograd.Function):
 def mesh_laplacian_loss(pred_pos, mesh, ltype="rmse"):
     """simple laplacian for output meshes (util/loss.py:37-53)."""
     _ltype(ltype, "rmse", ("mae", "rmse"))
-    tb = tables_for(mesh, pred_pos.device)
-    return _Lap.apply(pred_pos, tb, _target(mesh.vs, pred_pos.device))
+    with on_device(_pred(pred_pos, "pred_pos")):
+        tb = tables_for(mesh, pred_pos.device)
+        return _Lap.apply(pred_pos, tb, _target(mesh.vs, pred_pos.device))
 
 
 class _NormRec(torch.autograd.Function):
@@ -275,7 +316,8 @@ class _NormRec(torch.autograd.Function):
 def norm_rec_loss(pred_norm, real_norm, ltype="l1mae"):
     """reconstruction loss for (vertex, face) normal (util/loss.py:55-84)."""
     _ltype(ltype, "l1mae", ("l2mae", "l1mae", "l2rmse", "l1rmse", "cos"))
-    return _NormRec.apply(pred_norm, _target(real_norm, pred_norm.device))
+    with on_device(_pred(pred_norm, "pred_norm")):
+        return _NormRec.apply(pred_norm, _target(real_norm, pred_norm.device))
 
 
 class _Bnf(torch.autograd.Function):
@@ -306,12 +348,13 @@ class _Bnf(torch.autograd.Function):
 def fn_bnf_loss(pos, fn, mesh, ltype="l1mae", loop=5):
     """bilateral loss for face normal (util/loss.py:86-138); ``pos`` is treated as a constant."""
     _ltype(ltype, "l1mae", ("mae", "l1mae", "rmse", "l1rmse"))
-    dev = fn.device
-    if isinstance(pos, np.ndarray):
-        pos = torch.from_numpy(pos).to(dev)
-    tb = tables_for(mesh, dev)
-    zero_real = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
-    return _Bnf.apply(fn, _f32(pos, "pos"), tb, int(loop), zero_real)
+    dev = _pred(fn, "fn").device
+    with on_device(dev):
+        if isinstance(pos, np.ndarray):
+            pos = torch.from_numpy(pos).to(dev)
+        tb = tables_for(mesh, dev)
+        zero_real = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
+        return _Bnf.apply(fn, _f32(pos, "pos"), tb, int(loop), zero_real)
 
 
 class _PosNorm(torch.autograd.Function):
@@ -340,11 +383,13 @@ class _PosNorm(torch.autograd.Function):
 def pos_norm_loss(pos, norm, mesh, ltype="mae"):
     """loss between vertex position and face normal (util/loss.py:140-160)."""
     _ltype(ltype, "mae", ("mae", "rmse"))
-    dev = pos.device
-    tb = tables_for(mesh, dev)
-    zf = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
-    zv = torch.zeros((tb.V, 3), dtype=torch.float64, device=dev)
-    return _PosNorm.apply(pos, norm, tb, zf, zv)
+    dev = _pred(pos, "pos").device
+    _pred(norm, "norm")
+    with on_device(dev):
+        tb = tables_for(mesh, dev)
+        zf = torch.zeros((tb.F, 3), dtype=torch.float64, device=dev)
+        zv = torch.zeros((tb.V, 3), dtype=torch.float64, device=dev)
+        return _PosNorm.apply(pos, norm, tb, zf, zv)
 
 
 def mad(norm1, norm2):

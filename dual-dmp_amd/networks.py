@@ -37,18 +37,20 @@ class _EngineFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, arena, net):
         eng = net._engine
-        out = eng.forward(arena.detach(), update_running=net.training)
-        ctx.net = net
-        return out.clone()
+        with ops.on_device(eng.device):
+            out = eng.forward(arena.detach(), update_running=net.training)
+            ctx.net = net
+            return out.clone()
 
     @staticmethod
     def backward(ctx, dout):
         net = ctx.net
         eng = net._engine
-        eng.backward(net.arena.detach(), net._grad_arena, dout)
-        if eng.comm.world_size > 1:
-            net._reduce_grads()
-        return net._grad_arena.clone(), None
+        with ops.on_device(eng.device):
+            eng.backward(net.arena.detach(), net._grad_arena, dout)
+            if eng.comm.world_size > 1:
+                net._reduce_grads()
+            return net._grad_arena.clone(), None
 
 
 class _FusedNet(nn.Module):
@@ -153,7 +155,10 @@ class _FusedNet(nn.Module):
         raise ValueError("reorder must be 'morton', 'bfs' or None")
 
     def forward(self, data):
-        self._get_engine(data)
+        if self.device.type != "cuda":
+            raise ops.DdmpError("PosNet/NormalNet run on the HIP path only (device %s): there is no CPU fallback" % self.device)
+        with ops.on_device(self.device):
+            self._get_engine(data)
         return _EngineFn.apply(self.arena, self)
 
     def _reduce_grads(self):

@@ -52,6 +52,11 @@ class _GCNConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.on_device(dy):
+            return _GCNConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         saved, wp = ctx.saved_tensors
         graph, cin = ctx.graph, ctx.cin
         dy = dy.contiguous()
@@ -105,8 +110,11 @@ class GCNConv(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
         if x.dim() != 2 or x.shape[1] != self.in_channels:
             raise ValueError("GCNConv: expected x of shape [N, %d]" % self.in_channels)
-        graph = ops.graph_for(edge_index, x.shape[0])
-        return _GCNConvFn.apply(x, self.lin.weight, self.bias, graph)
+        if not x.is_cuda:
+            raise ops.DdmpError("GCNConv runs on the HIP path only: x must be a CUDA (ROCm) tensor, there is no CPU fallback")
+        with ops.on_device(x):
+            graph = ops.graph_for(edge_index, x.shape[0])
+            return _GCNConvFn.apply(x, self.lin.weight, self.bias, graph)
 
     def extra_repr(self):
         return "%d, %d" % (self.in_channels, self.out_channels)

@@ -25,6 +25,19 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def on_device(dev):
+    """Context manager: make ``dev`` (a tensor or a device) the current HIP device.  The C ABI launches on the current
+    device's stream and ``ddmp_graph`` allocates there; every module-level entry point (nets, GCNConv, losses,
+    trainers) enters this, so ``PosNet(torch.device("cuda:1"))`` works without a ``torch.cuda.set_device`` by the
+    caller (as the reference's ``PosNet(device)`` does)."""
+    if isinstance(dev, torch.Tensor):
+        dev = dev.device
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise DdmpError("the HIP path needs a CUDA (ROCm) device, got %s: there is no CPU fallback" % dev)
+    return torch.cuda.device(dev)
+
+
 class Profiler:
     """Per-call timing with HIP events recorded on the stream the kernels are launched on
     (torch's current stream), plus the ALGORITHMIC bytes / flops of each call.
@@ -98,6 +111,12 @@ def gemm_scales_roll(slots):
 def _chk(t, dtype=torch.float32, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise DdmpError("%s must be a CUDA (ROCm) tensor: the HIP path has no CPU fallback" % name)
+    if t.device.index != torch.cuda.current_device():
+        # the library launches on the CURRENT device's stream and allocates graphs there: a tensor of another device
+        # would be addressed from the wrong GPU.  The nets / trainers / losses enter `torch.cuda.device(their device)`
+        # themselves; a bare ops call has to be made under the tensor's device.
+        raise DdmpError("%s lives on cuda:%d but the current device is cuda:%d: wrap the call in "
+                        "`with torch.cuda.device(t.device):`" % (name, t.device.index, torch.cuda.current_device()))
     if t.dtype != dtype:
         raise DdmpError("%s must be %s, got %s" % (name, dtype, t.dtype))
     return t

@@ -124,6 +124,10 @@ class FusedTrainer:
         self.neng.check_scales()
 
     def step(self):
+        with ops.on_device(self.device):
+            return self._step()
+
+    def _step(self):
         self.epoch += 1
         self.t += 1
         gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0

@@ -11,6 +11,11 @@ import torch
 SLOPE = 0.01
 
 
+def on_device(dev):
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def _f(x, pro, slope):
     if pro is None:
         return x

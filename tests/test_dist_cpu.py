@@ -161,8 +161,9 @@ def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P):
     assert bad <= 1e-3 * tot, (bad, tot)
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, interleave="0"):
     try:
+        os.environ["DDMP_DIST_INTERLEAVE"] = interleave
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         import torch.distributed as dist
@@ -187,9 +188,11 @@ def _gloo_worker(rank, world, port, q):
         raise
 
 
-def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle):
+@pytest.mark.parametrize("interleave", ["0", "1"])
+def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave):
     """The real torch.distributed code path (all_to_all_single halo exchange, all_reduce of BN sums / gradients /
-    pos+norm) with world_size 2 over gloo."""
+    pos+norm) with world_size 2 over gloo; both the blocking default and the interleaved async_op=True form
+    (DDMP_DIST_INTERLEAVE=1)."""
     import torch.multiprocessing as mp
     import cpu_ops_stub as stub
     _patch(monkeypatch.setattr, stub)
@@ -197,8 +200,8 @@ def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle):
     ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 200)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + 200 * int(interleave)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
     [p.start() for p in procs]
     got = {}
     for _ in range(2):
