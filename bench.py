@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: training iterations/sec (+ MAD) of the Dual-DMP step on a synthetic 1M-face mesh.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,30 +9,73 @@ One "step" = main.py:88-110 of the reference (two GCN forwards, five losses, bac
 two Adam updates) + the loss.item() sync (main.py:113).  Inputs are resident in HBM before the timed region.
 Workload = BASELINE.json configs[2]: synthetic manifold mesh, 1,000,000 faces / 500,000 vertices (torus grid),
 unit mean edge, Gaussian noise 0.2 along vertex normals (seed 314), 30-step Laplacian smooth, z1 seed 314,
-weights seed 0, k=(3,4,4,4,1), bnfloop=1, lr 0.01, float32.  N > 1: the same mesh is face/vertex-partitioned
-over N ranks with 1-hop halos (strong scaling), see dual-dmp_amd/dist.py.
+weights seed 0, k=(3,4,4,4,1), bnfloop=1, lr 0.01.  --dtype f32 (default, the headline line) keeps float32
+features with float32-class split-MFMA GEMMs; --dtype bf16 is the bf16-feature mode (configs[1] arithmetic) on the
+same mesh.  N > 1: the same mesh is face/vertex-partitioned over N ranks with 1-hop halos (strong scaling, see
+dual-dmp_amd/dist.py); `--gpus N` without a torchrun environment starts the N ranks itself (child processes, before
+this process touches a GPU).
 
-Rank 0 prints ONE JSON line (schema in the task contract) with two extra objects:
-  roofline      dominant kernel family of the step (by summed time), measured with HIP events on the launch
-                stream in a separate profiled pass of the same step; + "roofline_gather" for the GCN gather
-  cpu_baseline  the oracle's PyG-shaped PyTorch-CPU training step timed on this host (bounded sample)
+Rank 0 prints ONE JSON line (schema in the task contract) with extra objects:
+  roofline            dominant kernel family of the step (by summed time), measured with HIP events on the launch
+                      stream in a separate profiled pass of the same step; + "roofline_gather" for the GCN gather
+  cpu_baseline        the oracle's PyG-shaped PyTorch-CPU training step timed on this host (bounded sample)
+  gate_open_ms_per_step, random_order_ms_per_step, eval_block_ms     SURVEY.md §8d's side figures (untimed region)
 """
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--faces", type=int, default=1000000)
+    ap.add_argument("--order", choices=["native", "random"], default="native",
+                    help="vertex/face numbering of the synthetic mesh as handed to the engine")
+    ap.add_argument("--bnfloop", type=int, default=1)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="feature dtype: f32 (headline line, BASELINE configs[2]) or bf16 features (configs[1] arithmetic)")
+    ap.add_argument("--overlap", type=int, default=1, help="1: PosNet on a second stream beside NormalNet")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the iteration as one hipGraph (single-GPU path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-faces", type=int, default=250000)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--extras", type=int, default=1,
+                    help="1: also measure (outside the timed region) gate-open iterations, a randomly numbered mesh and the eval block")
+    ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table (JSON) here")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (this process has not touched a
+    GPU: importing torch does not initialise HIP) and hand their single JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def load_oracle():
@@ -63,6 +106,7 @@ def build_case(faces, order):
 
 
 def _oracle_setup(oracle, faces):
+    import torch
     gt, noisy, smooth, _ = build_case(faces, "native")
     odata = oracle.OracleDataset(noisy, smooth)
     torch.manual_seed(0)
@@ -73,38 +117,50 @@ def _oracle_setup(oracle, faces):
     return lambda ep: oracle.train_step(pn, nn_, op, on, odata, noisy, args, ep), noisy
 
 
-def cpu_baseline(sample_faces, target_faces, iters=2):
-    """Oracle (PyG-shaped PyTorch CPU restatement) timed on this host, bounded to ~10-30 s: the thread count is
-    calibrated first (PyTorch's default = all cores thrashes on many-core hosts: 256 threads measured 40x slower
-    than 8 on this workload), then 1 warm-up + `iters` timed iterations of the same step on a smaller torus of
-    the same family; reported linearly extrapolated to the bench size (the step is O(faces))."""
+def cpu_baseline(sample_faces, target_faces, iters=3):
+    """Oracle (PyG-shaped PyTorch CPU restatement of main.py:88-110) timed on this host: 1 warm-up + `iters` timed
+    iterations at `sample_faces` (default 250,000 faces, SURVEY.md §8d's fall-back size: 1M faces needs ~75 GB and
+    minutes per iteration), reported linearly extrapolated to the bench size (the step is O(faces)).  The thread count is
+    calibrated first on a 20k-face probe and confirmed at the sample size between the two fastest candidates (PyTorch's
+    all-cores default thrashes on a many-core host: 256 threads measured 40x slower than 16 on this workload)."""
+    import resource
+    import torch
     oracle = load_oracle()
     ncpu = os.cpu_count() or 1
     cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
-    step, _ = _oracle_setup(oracle, 5000)
-    best, best_dt = cands[0], float("inf")
+    step, _ = _oracle_setup(oracle, 20000)
+    probe = {}
     for t in cands:
         torch.set_num_threads(t)
         step(1)
         t0 = time.perf_counter()
         step(2)
-        dt = time.perf_counter() - t0
-        if dt < best_dt:
-            best, best_dt = t, dt
-    torch.set_num_threads(best)
+        probe[t] = time.perf_counter() - t0
+    ranked = sorted(cands, key=lambda t: probe[t])
     step, noisy = _oracle_setup(oracle, sample_faces)
-    step(1)
+    F = len(noisy.faces)
+    torch.set_num_threads(ranked[0])
+    step(1)                                            # warm-up (allocator, index caches)
+    best, per_thread = ranked[0], {}
+    for t in ranked[:2]:                               # confirm at the sample size: one timed iteration each
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        step(2)
+        per_thread[t] = time.perf_counter() - t0
+    best = min(per_thread, key=per_thread.get)
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
-    for ep in range(2, 2 + iters):
+    for ep in range(3, 3 + iters):
         step(ep)
     dt = (time.perf_counter() - t0) / iters
-    F = len(noisy.faces)
+    rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     return {
         "value": (1.0 / dt) * F / target_faces, "unit": "iters/s", "cores": best, "kind": "port",
-        "sample": "oracle train_step (PyTorch CPU, PyG-shaped index_select*w+index_add per layer), %d faces / %d verts, "
-                  "%d threads (fastest of %s on a %d-core host), 1 warm-up + %d timed iters: %.3f s/iter = %.4f iters/s "
-                  "at that size; value = linear extrapolation to %d faces"
-                  % (F, len(noisy.vs), best, cands, ncpu, iters, dt, 1.0 / dt, target_faces),
+        "sample": "oracle train_step (PyTorch CPU, PyG-shaped index_select*w+index_add per layer, gcn_norm per call), %d faces / "
+                  "%d verts, %d threads (calibrated: 20k-face probe %s s/iter, at the sample size %s s/iter; %d-core host), 1 warm-up + "
+                  "%d timed iters: %.2f s/iter = %.4f iters/s at that size, peak RSS %.1f GB; value = linear extrapolation to %d faces"
+                  % (F, len(noisy.vs), best, {t: round(v, 2) for t, v in probe.items()}, {t: round(v, 2) for t, v in per_thread.items()},
+                     ncpu, iters, dt, 1.0 / dt, rss_gb, target_faces),
     }
 
 
@@ -117,15 +173,31 @@ def family_table(summary, steps):
     return fam
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate --pmc passes).
-    bench.py cannot run the profiler itself; None when no profile is committed."""
+def csrc_sha16():
+    """Content hash of the kernel sources: a PMC traffic file is only quoted for the sources it was measured on."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dual-dmp_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(p).encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(name, dtype):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_hbm_traffic*.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate --pmc passes,
+    scripts/pmc_traffic.py).  bench.py cannot run the profiler itself.  A file measured on OTHER kernel sources (its
+    csrc_sha16 differs from the tree's) or for the other feature dtype is refused: (None, reason)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic*.json")))
+    files = [f for f in files if json.load(open(f)).get("dtype", "f32") == dtype]
     if not files:
-        return None, None
+        return None, "no PMC profile committed for dtype %s" % dtype
     d = json.load(open(files[-1]))
+    if d.get("csrc_sha16") != csrc_sha16():
+        return None, "stale: %s was measured on other kernel sources (csrc %s, tree %s)" % (
+            os.path.basename(files[-1]), d.get("csrc_sha16"), csrc_sha16())
     tot_b = tot_n = 0.0
     for k in d.get("per_kernel", []):
         kn = k["kernel"]
@@ -135,16 +207,19 @@ def pmc_traffic(name):
         if fam == want or (name == "gemm" and fam.startswith("gemm_")):
             tot_b += (k["hbm_read_GB"] + k["hbm_write_GB"]) * 1e9
             tot_n += k["launches"]
-    return (round(tot_b / tot_n), os.path.basename(files[-1])) if tot_n else (None, None)
+    return (round(tot_b / tot_n), os.path.basename(files[-1])) if tot_n else (None, "kernel family not in " + os.path.basename(files[-1]))
 
 
-def roofline_obj(name, f):
+def roofline_obj(name, f, dtype):
     ms = f["ms"]
+    tb, tsrc = pmc_traffic(name, dtype)
     if name.startswith("gemm"):
         from dual_dmp_amd import ops
         mode = ops.get_gemm_mode()
-        f32_eq = f["flops"] / (ms * 1e-3) / 1e12          # algorithmic (f32) FLOP/s
-        if mode == 0:
+        f32_eq = f["flops"] / (ms * 1e-3) / 1e12          # algorithmic FLOP/s
+        if dtype == "bf16":
+            ach, peak, what = f32_eq, MFMA_BF16_PEAK_TF, "bf16 features: one v_mfma_f32_32x32x16_bf16 product per contraction step"
+        elif mode == 0:
             ach, peak, what = f32_eq, MFMA_F32_PEAK_TF, "f32-input MFMA"
         elif mode == 13:
             nprod = 3
@@ -154,8 +229,7 @@ def roofline_obj(name, f):
                 % (nprod, nprod, nprod))
         else:
             ach, peak, what = f32_eq * mode, MFMA_BF16_PEAK_TF, "bf16x%d split MFMA: %d bf16 MFMA products per f32 product" % (mode, mode)
-        tb, tsrc = pmc_traffic(name)
-        note = ("%s; the MFMA figures count the MFMA flops actually issued; algorithmic f32-equivalent rate = %.1f TFLOP/s "
+        note = ("%s; the MFMA figures count the MFMA flops actually issued; algorithmic rate = %.1f TFLOP/s "
                 "(= %.2f of the 157.3 TF f32-input-MFMA peak)" % (what, f32_eq, f32_eq / MFMA_F32_PEAK_TF))
         mfma = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
         gbs = f["bytes"] / (ms * 1e-3) / 1e9                # algorithmic bytes: operands read once, result written once
@@ -165,34 +239,36 @@ def roofline_obj(name, f):
         out = {"kernel": name}
         out.update(first)
         out.update({"traffic": tb, "traffic_source": tsrc, "other_roofline": other,
-                    "algorithmic_f32_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
+                    "algorithmic_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
                     "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
                     "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1)), "note": note})
         return out
     ach = f["bytes"] / (ms * 1e-3) / 1e9
-    tb, tsrc = pmc_traffic(name)
     return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tb, "traffic_source": tsrc,
             "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
             "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
 
 
+def timed_steps(tr, n, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = tr.step().item()
+    sync()
+    return (time.perf_counter() - t0) / n * 1e3, loss
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--faces", type=int, default=1000000)
-    ap.add_argument("--order", choices=["native", "random"], default="native",
-                    help="vertex/face numbering of the synthetic mesh as handed to the engine")
-    ap.add_argument("--bnfloop", type=int, default=1)
-    ap.add_argument("--overlap", type=int, default=1, help="1: PosNet on a second stream beside NormalNet")
-    ap.add_argument("--graph", type=int, default=1, help="1: replay the iteration as one hipGraph (single-GPU path)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-faces", type=int, default=20000)
-    ap.add_argument("--profile-steps", type=int, default=2)
-    ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table (JSON) here")
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        if "RANK" in os.environ:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d "
+                     "(or without a torchrun environment: bench.py starts the ranks itself)" % (args.gpus, world, args.gpus))
+        sys.exit(self_launch(args))
+    import numpy as np
+    import torch
 
     # stdout carries exactly ONE line, the JSON result: everything else this process or the libraries under it
     # write to fd 1 (the RCCL version banner, for one) goes to stderr.
@@ -200,10 +276,8 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -212,47 +286,56 @@ def main():
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
 
+    fdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     force_dist = os.environ.get("DDMP_FORCE_DIST") == "1"      # exercise the RCCL path at world_size 1
-    if world > 1 or force_dist:
+    multi = world > 1 or force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def make_trainer(noisy, smooth, data):
+        torch.manual_seed(0)
+        if multi:
+            from dual_dmp_amd.dist import make_distributed_trainer
+            nets = (PosNet(dev, dtype=fdt), NormalNet(dev, dtype=fdt))
+            return make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop, nets=nets)
+        posnet, normnet = PosNet(dev, dtype=fdt), NormalNet(dev, dtype=fdt)
+        data.to(dev)
+        return FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph),
+                            overlap=bool(args.overlap))
+
     t_setup = time.perf_counter()
     gt, noisy, smooth, data = build_case(args.faces, args.order)
     V, F = len(noisy.vs), len(noisy.faces)
-    torch.manual_seed(0)
-    if world > 1 or force_dist:
-        from dual_dmp_amd.dist import make_distributed_trainer
-        tr = make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop)
-        barrier = tr.barrier
-    else:
-        posnet, normnet = PosNet(dev), NormalNet(dev)
-        data.to(dev)
-        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph), overlap=bool(args.overlap))
-        barrier = lambda: None   # noqa: E731
+    tr = make_trainer(noisy, smooth, data)
+    barrier = tr.barrier if multi else (lambda: None)
     setup_s = time.perf_counter() - t_setup
+
+    def sync():
+        barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         tr.step().item()
-    barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step().item()          # the reference's per-step sync (main.py:113)
-    barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     scale_overflow = None                # f16x3 GEMM mode: did an operand outgrow its scale (values clamped)?
     try:
         tr.check_scales()
     except OverflowError as e:
         scale_overflow = str(e)
-    if world > 1 or force_dist:
+    if multi:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, 1.0 if scale_overflow else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if float(t[1].item()) > 0 and not scale_overflow:
+            scale_overflow = "raised on another rank"
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- MAD (outside the timed region): float32 positions -> face normals -> mean angular difference
@@ -260,7 +343,7 @@ def main():
     if rank == 0:
         from dual_dmp_amd.loss import mad
         from dual_dmp_amd.mesh import Mesh
-        pos = tr.gather_pos().cpu().numpy() if (world > 1 or force_dist) else tr.pos.cpu().numpy()
+        pos = tr.gather_pos().cpu().numpy() if multi else tr.pos.cpu().numpy()
         o = Mesh.__new__(Mesh)
         o.vs, o.faces = pos.astype(np.float64), noisy.faces
         Mesh.compute_face_normals(o)
@@ -269,22 +352,45 @@ def main():
     elif world > 1:
         tr.gather_pos()
 
+    # ---- side figures of SURVEY.md §8d (single-GPU path, outside the timed region)
+    if args.extras and not multi:
+        from dual_dmp_amd.evaluate import Evaluator
+        ev = Evaluator(noisy, gt.fn, dev)
+        ev.mad(tr.pos)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mad_dev = ev.mad(tr.pos)                   # face normals + MAD on the device, one scalar back (main.py:117-123)
+        out["eval_block_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        out["mad_deg"]["device_evaluator"] = round(mad_dev, 4)
+        # iterations 101..: the BNF gate is open (main.py:101-102), its backward runs
+        tr.epoch = max(tr.epoch, tr.bnf_start_epoch)
+        for _ in range(3):
+            tr.step().item()
+        out["gate_open_ms_per_step"] = round(timed_steps(tr, max(5, args.steps // 2), sync)[0], 3)
+        out["gate_open_note"] = "epochs > %d: k4 * fn_bnf_loss takes part in the backward (bnfloop=%d)" % (tr.bnf_start_epoch, args.bnfloop)
+
     # ---- profiled pass (separate from the timed region): HIP events around every launch
     roof = roof_gather = None
     table = {}
     if args.profile_steps > 0:
-        ops.PROF = ops.Profiler()
         if hasattr(tr, "use_graph"):
             tr.use_graph = False             # per-launch events need the eager path
             tr.overlap = False
             tr.peng.async_wgrad = tr.neng.async_wgrad = False
+        tr.step().item()
+        ops.PROF = ops.Profiler()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for _ in range(args.profile_steps):
             tr.step().item()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / args.profile_steps * 1e3
         summ = ops.PROF.summary()
         ops.PROF = None
         fam = family_table(summ, args.profile_steps)
         if rank == 0:
-            # the three GEMM forms (forward NT, dgrad NN, wgrad TN) are one kernel family on one roofline (MFMA)
+            # the three GEMM forms (forward NT, dgrad NN, wgrad TN) are one kernel family on one roofline
             gem = dict(calls=0, ms=0.0, bytes=0.0, flops=0.0)
             for k_, f_ in fam.items():
                 if k_.startswith("gemm"):
@@ -294,11 +400,11 @@ def main():
             if gem["ms"] > 0:
                 cand["gemm"] = gem
             dom = max(cand.items(), key=lambda kv: kv[1]["ms"])
-            roof = roofline_obj(*dom)
+            roof = roofline_obj(dom[0], dom[1], args.dtype)
             if dom[0] == "gemm":
                 roof["forms_ms_per_step"] = {k_: round(f_["ms"], 3) for k_, f_ in fam.items() if k_.startswith("gemm")}
             if "spmm" in fam:
-                roof_gather = roofline_obj("spmm", fam["spmm"])
+                roof_gather = roofline_obj("spmm", fam["spmm"], args.dtype)
             for (name, key), a in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 ms = a["ms"] / args.profile_steps
                 table["%s%s" % (name, list(key) if isinstance(key, tuple) else [key])] = {
@@ -307,25 +413,45 @@ def main():
                     "alg_GBs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1) if a["ms"] > 0 else 0,
                     "TFLOPs": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2) if a["ms"] > 0 else 0}
             out["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+            out["kernel_ms_sum"] = round(sum(v["ms"] for v in fam.values()), 3)
+            out["kernel_ms_note"] = ("profiled pass: eager, ONE stream (%.2f ms per step wall); the timed step replays one hipGraph "
+                                     "with PosNet on a second stream, so the families overlap there" % eager_ms)
+
+    # ---- the same step on a randomly numbered mesh (worst-case input locality; the engine relabels along a Morton curve)
+    if args.extras and not multi and args.order == "native":
+        del tr
+        torch.cuda.empty_cache()
+        gt2, noisy2, smooth2, data2 = build_case(args.faces, "random")
+        tr2 = make_trainer(noisy2, smooth2, data2)
+        for _ in range(3):
+            tr2.step().item()
+        out["random_order_ms_per_step"] = round(timed_steps(tr2, max(5, args.steps // 2), sync)[0], 3)
+        del tr2
+        torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_sample_faces, F)
+        cpu = cpu_baseline(args.cpu_sample_faces, F, args.cpu_iters)
 
     if rank == 0:
+        arith = ("bf16 features: bf16 activations / activation gradients in HBM, one bf16 MFMA product per step, f32 accumulate, "
+                 "f32 parameters, f64 BatchNorm statistics") if args.dtype == "bf16" else {
+            6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA",
+            13: "f16x3 split MFMA on scaled operands, f32 accumulate (f32-class accuracy; bf16x6 in the narrow layers)",
+        }[ops.get_gemm_mode()]
         line = {
             "metric": "training iters/sec + MAD score, 1M-face mesh @ 1/2/4/8 MI355X",
             "value": round(args.steps / elapsed, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "gemm_arithmetic": {6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA",
-                                13: "f16x3 split MFMA on scaled operands, f32 accumulate (f32-class accuracy; bf16x6 in the narrow layers)",
-                                }[ops.get_gemm_mode()],
-            "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, float32, k=(3,4,4,4,1), "
-                                   "bnfloop=%d, %s numbering (BASELINE.json configs[2])" % (F, V, args.bnfloop, args.order),
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "gemm_arithmetic": arith,
+            "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, %s features, k=(3,4,4,4,1), "
+                                   "bnfloop=%d, %s numbering (BASELINE.json configs[2]%s)"
+                                   % (F, V, "float32" if args.dtype == "f32" else "bfloat16", args.bnfloop, args.order,
+                                      "" if args.dtype == "f32" else "; the bf16-feature arithmetic of configs[1]"),
                        "faces": F, "verts": V, "parallelism": "1 GPU" if world == 1 else "%d-way face/vertex partition + 1-hop halo" % world,
-                       "setup_s": round(setup_s, 1), "hipgraph_replay": bool(args.graph) and world == 1 and not force_dist,
-                       "two_streams": bool(args.overlap) and world == 1 and not force_dist},
+                       "setup_s": round(setup_s, 1), "hipgraph_replay": bool(args.graph) and not multi,
+                       "two_streams": bool(args.overlap) and not multi},
             "loss": round(float(loss), 6),
             "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
             "gemm_scale_overflow": scale_overflow,
@@ -337,7 +463,7 @@ def main():
                 json.dump({"config": line["config"], "ms_per_step": line["ms_per_step"], "kernels": table}, fh, indent=1)
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     os.close(result_fd)
-    if world > 1 or force_dist:
+    if multi:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -40,6 +40,9 @@ def get_parser(real: bool):
         p.add_argument("--port", type=int, default=8080)
     p.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly on one stream (default: one hipGraph per iteration, PosNet and NormalNet on two streams)")
     p.add_argument("--seed", type=int, default=None, help="torch seed for the weight init (the reference is unseeded)")
+    p.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                   help="feature dtype in HBM: fp32 (default, float32-class arithmetic) or bf16 features "
+                        "(bfloat16 activations / activation gradients, float32 parameters and accumulation)")
     return p
 
 
@@ -62,7 +65,8 @@ def run(argv=None, real: bool = False):
     torch.cuda.set_device(device)
     if args.seed is not None:
         torch.manual_seed(args.seed)
-    posnet, normnet = PosNet(device).to(device), NormalNet(device).to(device)
+    fdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    posnet, normnet = PosNet(device, dtype=fdt).to(device), NormalNet(device, dtype=fdt).to(device)
     dataset.to(device)
     tr = FusedTrainer(posnet, normnet, dataset, n_mesh, pos_lr=args.pos_lr, norm_lr=args.norm_lr,
                       k=(args.k1, args.k2, args.k3, args.k4, args.k5), grad_crip=args.grad_crip, bnfloop=args.bnfloop,

@@ -12,7 +12,7 @@
 //                     of dY (= gradient of the conv bias, analytically 0 after BN).
 //
 // Column layout: C/4 lanes (float4) per row, 256/(C/4) rows per workgroup step, grid-stride over rows.
-#include "ddmp_common.h"
+#include "b16_common.h"
 
 #include <algorithm>
 
@@ -22,95 +22,135 @@ using namespace ddmp;
 
 constexpr int kMaxBlocks = 1024;
 
+// element access of the two feature dtypes: VW consecutive columns per lane (16 bytes)
+template <typename T> struct El;
+template <> struct El<float> {
+    static constexpr int VW = 4;
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float* p, float (&v)[4]) { nt_store4(p, make_float4(v[0], v[1], v[2], v[3])); }
+};
+template <> struct El<bf16_t> {
+    static constexpr int VW = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) { bf_unpack8(ld8b(p), v); }
+    static __device__ __forceinline__ void st(bf16_t* p, float (&v)[8]) {       // v <- the values as stored (rounded)
+        const uint4 o = bf_pack8(v);
+        nt_st8b(p, o);
+        bf_unpack8(o, v);
+    }
+};
+template <int VW> __device__ __forceinline__ void ldc(const float* p, float (&v)[VW]) {
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
 __host__ __device__ inline bool width_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
 
-int colreduce_blocks(int64_t n_rows, int C) {
-    const int rpi = 256 / (C / 4);
+int colreduce_blocks(int64_t n_rows, int C, int VW = 4) {
+    const int rpi = 256 / (C / VW);
     return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, cdiv(n_rows, (int64_t)rpi * 4)));
 }
 
-// F::operator()(row, c0, s0[4], s1[4]) accumulates two per-column quantities for columns c0..c0+3
+// F::operator()(row, c0, s0[VW], s1[VW]) accumulates two per-column quantities for columns c0..c0+VW-1
+// (VW = F::VW = 4 float32 | 8 bfloat16 columns per lane; C >= 2 VW so that a row takes at most 128 lanes)
 template <class F>
 __global__ __launch_bounds__(256) void colreduce_kernel(F f, int n_rows, int C, double* __restrict__ partial) {
-    __shared__ double sm[2 * 1024];
-    const int lpr = C >> 2, rpi = 256 / lpr;
+    constexpr int VW = F::VW;
+    __shared__ double sm[2 * 1024 * (VW / 4)];
+    constexpr int kHalf = 1024 * (VW / 4);
+    const int lpr = C / VW, rpi = 256 / lpr;
     const int tid = threadIdx.x, sl = tid % lpr, rg = tid / lpr;
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    for (int row = blockIdx.x * rpi + rg; row < n_rows; row += gridDim.x * rpi) f(row, sl * 4, s0, s1);
+    double s0[VW], s1[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) s0[k] = s1[k] = 0.0;
+    for (int row = blockIdx.x * rpi + rg; row < n_rows; row += gridDim.x * rpi) f(row, sl * VW, s0, s1);
     // sm[v][rg][c]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sm[rg * C + sl * 4 + k] = s0[k];
-        sm[1024 + rg * C + sl * 4 + k] = s1[k];
+    for (int k = 0; k < VW; ++k) {
+        sm[rg * C + sl * VW + k] = s0[k];
+        sm[kHalf + rg * C + sl * VW + k] = s1[k];
     }
     __syncthreads();
     for (int o = tid; o < 2 * C; o += 256) {
         const int v = o / C, c = o % C;
         double t = 0.0;
-        for (int r = 0; r < rpi; ++r) t += sm[v * 1024 + r * C + c];
+        for (int r = 0; r < rpi; ++r) t += sm[v * kHalf + r * C + c];
         partial[(int64_t)blockIdx.x * 2 * C + o] = t;
     }
 }
 
-struct StatsF {
-    const float* Y;
+template <typename T> struct StatsF {
+    static constexpr int VW = El<T>::VW;
+    const T* Y;
     int64_t ldy;
     __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
-        const float4 v = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + c0);
-        const double a = v.x, b = v.y, c = v.z, d = v.w;
-        s0[0] += a; s0[1] += b; s0[2] += c; s0[3] += d;
-        s1[0] = fma(a, a, s1[0]); s1[1] = fma(b, b, s1[1]); s1[2] = fma(c, c, s1[2]); s1[3] = fma(d, d, s1[3]);
+        float v[VW];
+        El<T>::ld(Y + (int64_t)row * ldy + c0, v);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            const double a = v[k];
+            s0[k] += a;
+            s1[k] = fma(a, a, s1[k]);
+        }
     }
 };
 
-struct BwdReduceF {
-    const float *dZ, *Y, *scale, *shift, *mean, *rstd;
+template <typename T> struct BwdReduceF {
+    static constexpr int VW = El<T>::VW;
+    const T *dZ, *Y;
+    const float *scale, *shift, *mean, *rstd;
     int64_t lddz, ldy;
     float slope;
     __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
-        const float4 dz = *reinterpret_cast<const float4*>(dZ + (int64_t)row * lddz + c0);
-        const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + c0);
-        const float4 a = *reinterpret_cast<const float4*>(scale + c0);
-        const float4 b = *reinterpret_cast<const float4*>(shift + c0);
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c0);
-        const float4 rs = *reinterpret_cast<const float4*>(rstd + c0);
-        const float g0 = dz.x * lrelu_grad(fmaf(y.x, a.x, b.x), slope);
-        const float g1 = dz.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope);
-        const float g2 = dz.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope);
-        const float g3 = dz.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope);
-        s0[0] += g0; s0[1] += g1; s0[2] += g2; s0[3] += g3;
-        s1[0] = fma((double)g0, (double)((y.x - mu.x) * rs.x), s1[0]);
-        s1[1] = fma((double)g1, (double)((y.y - mu.y) * rs.y), s1[1]);
-        s1[2] = fma((double)g2, (double)((y.z - mu.z) * rs.z), s1[2]);
-        s1[3] = fma((double)g3, (double)((y.w - mu.w) * rs.w), s1[3]);
+        float dz[VW], y[VW], a[VW], b[VW], mu[VW], rs[VW];
+        El<T>::ld(dZ + (int64_t)row * lddz + c0, dz);
+        El<T>::ld(Y + (int64_t)row * ldy + c0, y);
+        ldc<VW>(scale + c0, a);
+        ldc<VW>(shift + c0, b);
+        ldc<VW>(mean + c0, mu);
+        ldc<VW>(rstd + c0, rs);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            const float g = dz[k] * lrelu_grad(fmaf(y[k], a[k], b[k]), slope);
+            s0[k] += g;
+            s1[k] = fma((double)g, (double)((y[k] - mu[k]) * rs[k]), s1[k]);
+        }
     }
 };
 
 // column sums of dY produced on the fly (bias gradient); second slot unused
-struct BwdApplyF {
-    const float *dZ, *Y, *scale, *shift, *c1, *c0;
-    float* dY;
+template <typename T> struct BwdApplyF {
+    static constexpr int VW = El<T>::VW;
+    const T *dZ, *Y;
+    const float *scale, *shift, *c1, *c0;
+    T* dY;
     int64_t lddz, ldy, lddy;
     float slope;
     __device__ __forceinline__ void operator()(int row, int cc, double* s0, double* s1) const {
-        const float4 dz = *reinterpret_cast<const float4*>(dZ + (int64_t)row * lddz + cc);
-        const float4 y = *reinterpret_cast<const float4*>(Y + (int64_t)row * ldy + cc);
-        const float4 a = *reinterpret_cast<const float4*>(scale + cc);
-        const float4 b = *reinterpret_cast<const float4*>(shift + cc);
-        const float4 k1 = *reinterpret_cast<const float4*>(c1 + cc);
-        const float4 k0 = *reinterpret_cast<const float4*>(c0 + cc);
-        float4 o;
-        o.x = fmaf(a.x, dz.x * lrelu_grad(fmaf(y.x, a.x, b.x), slope), fmaf(k1.x, y.x, k0.x));
-        o.y = fmaf(a.y, dz.y * lrelu_grad(fmaf(y.y, a.y, b.y), slope), fmaf(k1.y, y.y, k0.y));
-        o.z = fmaf(a.z, dz.z * lrelu_grad(fmaf(y.z, a.z, b.z), slope), fmaf(k1.z, y.z, k0.z));
-        o.w = fmaf(a.w, dz.w * lrelu_grad(fmaf(y.w, a.w, b.w), slope), fmaf(k1.w, y.w, k0.w));
-        nt_store4(dY + (int64_t)row * lddy + cc, o);
-        s0[0] += o.x; s0[1] += o.y; s0[2] += o.z; s0[3] += o.w;
+        float dz[VW], y[VW], a[VW], b[VW], k1[VW], k0[VW], o[VW];
+        El<T>::ld(dZ + (int64_t)row * lddz + cc, dz);
+        El<T>::ld(Y + (int64_t)row * ldy + cc, y);
+        ldc<VW>(scale + cc, a);
+        ldc<VW>(shift + cc, b);
+        ldc<VW>(c1 + cc, k1);
+        ldc<VW>(c0 + cc, k0);
+#pragma unroll
+        for (int k = 0; k < VW; ++k)
+            o[k] = fmaf(a[k], dz[k] * lrelu_grad(fmaf(y[k], a[k], b[k]), slope), fmaf(k1[k], y[k], k0[k]));
+        El<T>::st(dY + (int64_t)row * lddy + cc, o);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) s0[k] += o[k];
         (void)s1;
     }
 };
 
 struct ColsumF {
+    static constexpr int VW = 4;
     const float* X;
     int64_t ldx;
     __device__ __forceinline__ void operator()(int row, int c0, double* s0, double* s1) const {
@@ -208,10 +248,29 @@ __global__ __launch_bounds__(256) void bn_lrelu_apply_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void bn_lrelu_apply_b16_kernel(const bf16_t* __restrict__ Y, int64_t ldy,
+                                                                 bf16_t* __restrict__ Z, int64_t ldz, int64_t n_rows, int C,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float slope) {
+    const int q = C >> 3;
+    const int64_t total = n_rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / q;
+        const int c0 = (int)(i % q) * 8;
+        float v[8], a[8], b[8];
+        bf_unpack8(ld8b(Y + row * ldy + c0), v);
+        ld8f(scale + c0, a);
+        ld8f(shift + c0, b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = lrelu(fmaf(v[k], a[k], b[k]), slope);
+        st8b(Z + row * ldz + c0, bf_pack8(v));
+    }
+}
+
 template <class F>
 int run_colreduce(const F& f, int64_t n_rows, int C, int width, double* out, void* ws, size_t ws_bytes,
                   hipStream_t st) {
-    const int nblk = colreduce_blocks(n_rows, C);
+    const int nblk = colreduce_blocks(n_rows, C, F::VW);
     if (!ws || ws_bytes < (size_t)nblk * 2 * C * sizeof(double)) return DDMP_EWORKSPACE;
     double* partial = (double*)ws;
     hipLaunchKernelGGL((colreduce_kernel<F>), dim3(nblk), dim3(256), 0, st, f, (int)n_rows, C, partial);
@@ -235,7 +294,7 @@ extern "C" size_t ddmp_colreduce_workspace_bytes(int64_t n_rows, int C) {
 extern "C" int ddmp_bn_stats_f32(const float* Y, int64_t ldy, int64_t n_rows, int C, double* sums,
                                  void* ws, size_t ws_bytes, ddmp_stream stream) {
     ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && ldy % 4 == 0);
-    StatsF f{Y, ldy};
+    StatsF<float> f{Y, ldy};
     return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -271,7 +330,7 @@ extern "C" int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float
                                       void* ws, size_t ws_bytes, ddmp_stream stream) {
     ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && lddz >= C && ldy % 4 == 0 && lddz % 4 == 0);
-    BwdReduceF f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
+    BwdReduceF<float> f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
     return run_colreduce(f, n_rows, C, 2 * C, sums2, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -292,7 +351,7 @@ extern "C" int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float*
     ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0 && dbias_sums);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C));
     ARG_TRY(ldy >= C && lddz >= C && lddy >= C && ldy % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0);
-    BwdApplyF f{dZ, Y, scale, shift, c1, c0, dY, lddz, ldy, lddy, slope};
+    BwdApplyF<float> f{dZ, Y, scale, shift, c1, c0, dY, lddz, ldy, lddy, slope};
     // result buffer [2C] sits behind the partials in the workspace; only the first C are the column sums
     const int nblk = colreduce_blocks(n_rows, C);
     const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
@@ -321,6 +380,58 @@ extern "C" int ddmp_colsum_f32(const float* X, int64_t ldx, int64_t n_rows, int 
 extern "C" int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_stream stream) {
     ARG_TRY(in && out && n > 0 && n < INT32_MAX);
     hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, (int)n);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+
+// ---------------------------------------------------------------- bfloat16 features (b16_common.h): same passes, 8 columns
+// per lane, float32 arithmetic, float64 sums; C a power of two in [16, 1024]; workspace = ddmp_colreduce_workspace_bytes
+extern "C" int ddmp_bn_stats_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, int C, double* sums, void* ws,
+                                  size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && ldy % 8 == 0 && b16_aligned(Y));
+    StatsF<bf16_t> f{Y, ldy};
+    return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ddmp_bn_bwd_reduce_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, int64_t n_rows,
+                                       int C, const float* scale, const float* shift, const float* mean,
+                                       const float* rstd, float slope, double* sums2, void* ws, size_t ws_bytes,
+                                       ddmp_stream stream) {
+    ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
+    ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && lddz >= C && ldy % 8 == 0 && lddz % 8 == 0);
+    ARG_TRY(b16_aligned(dZ) && b16_aligned(Y));
+    BwdReduceF<bf16_t> f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
+    return run_colreduce(f, n_rows, C, 2 * C, sums2, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ddmp_bn_bwd_apply_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, uint16_t* dY,
+                                      int64_t lddy, int64_t n_rows, int C, const float* scale, const float* shift,
+                                      const float* c1, const float* c0, float slope, double* dbias_sums, void* ws,
+                                      size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0 && dbias_sums);
+    ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16);
+    ARG_TRY(ldy >= C && lddz >= C && lddy >= C && ldy % 8 == 0 && lddz % 8 == 0 && lddy % 8 == 0);
+    ARG_TRY(b16_aligned(dZ) && b16_aligned(Y) && b16_aligned(dY));
+    BwdApplyF<bf16_t> f{dZ, Y, scale, shift, c1, c0, dY, lddz, ldy, lddy, slope};
+    const int nblk = colreduce_blocks(n_rows, C, 8);
+    const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
+    if (!ws || ws_bytes < need) return DDMP_EWORKSPACE;
+    double* tmp = (double*)ws + (size_t)nblk * 2 * C;
+    int st = run_colreduce(f, n_rows, C, C, tmp, ws, (size_t)nblk * 2 * C * sizeof(double), (hipStream_t)stream);
+    if (st != DDMP_OK) return st;
+    HIP_TRY(hipMemcpyAsync(dbias_sums, tmp, sizeof(double) * (size_t)C, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_bn_lrelu_apply_bf16(const uint16_t* Y, int64_t ldy, uint16_t* Z, int64_t ldz, int64_t n_rows, int C,
+                                        const float* scale, const float* shift, float slope, ddmp_stream stream) {
+    ARG_TRY(Y && Z && scale && shift && n_rows > 0 && C > 0 && C % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 && ldy >= C && ldz >= C);
+    ARG_TRY(b16_aligned(Y) && b16_aligned(Z));
+    const int64_t total = n_rows * (C / 8);
+    const int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 8);
+    hipLaunchKernelGGL(bn_lrelu_apply_b16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Y, ldy, Z, ldz, n_rows, C,
+                       scale, shift, slope);
     LAUNCH_TRY();
     return DDMP_OK;
 }

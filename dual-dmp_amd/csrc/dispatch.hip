@@ -1,0 +1,123 @@
+// dtype-tagged entry points (include/ddmp_hip.h, "dtype-tagged forms"): `void*` features + DDMP_F32 | DDMP_BF16.
+// Pure dispatch onto the typed functions; plus the two conversion kernels of the bf16-feature mode.
+#include "b16_common.h"
+
+#include <algorithm>
+
+namespace {
+using namespace ddmp;
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const __bf16 b = (__bf16)in[i];
+        out[i] = __builtin_bit_cast(unsigned short, b);
+    }
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = __uint_as_float((unsigned)in[i] << 16);
+}
+inline bool dt_ok(int dtype) { return dtype == DDMP_F32 || dtype == DDMP_BF16; }
+typedef const float* cf;
+typedef const uint16_t* cb;
+}  // namespace
+
+extern "C" int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream) {
+    ARG_TRY(in && out && n > 0);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+extern "C" int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream) {
+    ARG_TRY(in && out && n > 0);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_spmm(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+                         const float* bias, const float* ps, const float* psh, float slope, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_spmm_bf16(g, (cb)X, ldx, (uint16_t*)Y, ldy, C, bias, ps, psh, slope, st)
+                              : ddmp_spmm_f32(g, (cf)X, ldx, (float*)Y, ldy, C, bias, ps, psh, slope, st);
+}
+extern "C" size_t ddmp_spmm_bnred_ws_bytes(int64_t n_rows, int C, int dtype) {
+    return dtype == DDMP_BF16 ? ddmp_spmm_bnred_bf16_workspace_bytes(n_rows, C) : ddmp_spmm_bnred_workspace_bytes(n_rows, C);
+}
+extern "C" int ddmp_spmm_bnred(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+                               const void* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
+                               const float* rstd, float slope, double* sums2, void* ws, size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16
+               ? ddmp_spmm_bnred_bf16(g, (cb)X, ldx, (uint16_t*)Y, ldy, C, (cb)Yp, ldyp, scale, shift, mean, rstd, slope, sums2, ws, wsb, st)
+               : ddmp_spmm_bnred_f32(g, (cf)X, ldx, (float*)Y, ldy, C, (cf)Yp, ldyp, scale, shift, mean, rstd, slope, sums2, ws, wsb, st);
+}
+extern "C" int ddmp_spmm_bnbwd(const ddmp_graph* g, const void* dZ, int64_t lddz, const void* Yb, int64_t ldyb, void* out,
+                               int64_t ld_out, int C, int dtype, const float* a, const float* b, const float* c1,
+                               const float* c0, float slope, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_spmm_bnbwd_bf16(g, (cb)dZ, lddz, (cb)Yb, ldyb, (uint16_t*)out, ld_out, C, a, b, c1, c0, slope, st)
+                              : ddmp_spmm_bnbwd_f32(g, (cf)dZ, lddz, (cf)Yb, ldyb, (float*)out, ld_out, C, a, b, c1, c0, slope, st);
+}
+extern "C" size_t ddmp_gemm_rows_ws_bytes(int K, int M, int dtype) {
+    return dtype == DDMP_BF16 ? ddmp_gemm_rows_bf16_workspace_bytes(K, M) : ddmp_gemm_rows_workspace_bytes(K, M);
+}
+extern "C" int ddmp_gemm_nt(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n, int K,
+                            int M, int dtype, const float* bias, const float* ps, const float* psh, float slope, void* ws,
+                            size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_gemm_nt_bf16((cb)A, lda, W, ldw, (uint16_t*)Y, ldy, n, K, M, bias, ps, psh, slope, ws, wsb, st)
+                              : ddmp_gemm_nt_f32((cf)A, lda, W, ldw, (float*)Y, ldy, n, K, M, bias, ps, psh, slope, ws, wsb, st);
+}
+extern "C" int ddmp_gemm_nn(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n, int M,
+                            int K, int dtype, void* ws, size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_gemm_nn_bf16((cb)A, lda, W, ldw, (uint16_t*)Y, ldy, n, M, K, ws, wsb, st)
+                              : ddmp_gemm_nn_f32((cf)A, lda, W, ldw, (float*)Y, ldy, n, M, K, ws, wsb, st);
+}
+extern "C" size_t ddmp_gemm_tn_ws_bytes(int64_t n_rows, int M, int K, int dtype) {
+    return dtype == DDMP_BF16 ? ddmp_gemm_tn_bf16_workspace_bytes(n_rows, M, K) : ddmp_gemm_tn_workspace_bytes(n_rows, M, K);
+}
+extern "C" int ddmp_gemm_tn(const void* G, int64_t ldg, const void* Z, int64_t ldz, float* dW, int64_t lddw, int64_t n, int M,
+                            int K, int dtype, const float* ps, const float* psh, float slope, void* ws, size_t wsb,
+                            ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_gemm_tn_bf16((cb)G, ldg, (cb)Z, ldz, dW, lddw, n, M, K, ps, psh, slope, ws, wsb, st)
+                              : ddmp_gemm_tn_f32((cf)G, ldg, (cf)Z, ldz, dW, lddw, n, M, K, ps, psh, slope, ws, wsb, st);
+}
+extern "C" int ddmp_bn_stats(const void* Y, int64_t ldy, int64_t n, int C, int dtype, double* sums, void* ws, size_t wsb,
+                             ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_bn_stats_bf16((cb)Y, ldy, n, C, sums, ws, wsb, st) : ddmp_bn_stats_f32((cf)Y, ldy, n, C, sums, ws, wsb, st);
+}
+extern "C" int ddmp_bn_bwd_reduce(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t n, int C, int dtype,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd, float slope,
+                                  double* sums2, void* ws, size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_bn_bwd_reduce_bf16((cb)dZ, lddz, (cb)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st)
+                              : ddmp_bn_bwd_reduce_f32((cf)dZ, lddz, (cf)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st);
+}
+extern "C" int ddmp_bn_bwd_apply(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, void* dY, int64_t lddy, int64_t n,
+                                 int C, int dtype, const float* scale, const float* shift, const float* c1, const float* c0,
+                                 float slope, double* dbias_sums, void* ws, size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16
+               ? ddmp_bn_bwd_apply_bf16((cb)dZ, lddz, (cb)Y, ldy, (uint16_t*)dY, lddy, n, C, scale, shift, c1, c0, slope, dbias_sums, ws, wsb, st)
+               : ddmp_bn_bwd_apply_f32((cf)dZ, lddz, (cf)Y, ldy, (float*)dY, lddy, n, C, scale, shift, c1, c0, slope, dbias_sums, ws, wsb, st);
+}
+extern "C" int ddmp_head_fwd(const void* Y, int64_t ldy, int64_t n, int dtype, const float* scale, const float* shift,
+                             float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                             const float* x_pos, float* out, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_head_fwd_bf16((cb)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, x_pos, out, st)
+                              : ddmp_head_fwd_f32((cf)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, x_pos, out, st);
+}
+extern "C" int ddmp_head_bwd(const void* Y, int64_t ldy, int64_t n, int dtype, const float* scale, const float* shift,
+                             float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                             const float* dout, void* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
+                             void* ws, size_t wsb, ddmp_stream st) {
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16
+               ? ddmp_head_bwd_bf16((cb)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, dout, (uint16_t*)dZ, lddz, dW1, db1, dW2, db2, ws, wsb, st)
+               : ddmp_head_bwd_f32((cf)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, dout, (float*)dZ, lddz, dW1, db1, dW2, db2, ws, wsb, st);
+}

@@ -1,0 +1,633 @@
+// Dense steps of GCNConv on bfloat16 features (bf16-feature mode, b16_common.h): GCNConv.lin and its autograd
+// (util/networks.py:51-62 of the reference through PyG 2.2.0: X.W^T, dH.W, dH^T.X) with bf16 activations / activation
+// gradients in HBM, float32 master weights, ONE v_mfma_f32_32x32x16_bf16 product per contraction step (no operand
+// splitting, no scale slots), float32 accumulation, float32 weight gradients.
+//
+//   nt : Y[n,M]  = bf16( f(A[n,K]) . W[M,K]^T + bias )        forward (f = BatchNorm+LeakyReLU prologue, optional)
+//   nn : Y[n,K]  = bf16( A[n,M] . W[M,K] )                    dgrad
+//   tn : dW[M,K] = G[n,M]^T . f(Z[n,K])                       wgrad (float32 out, rows split over workgroups)
+//
+// At bf16 MFMA rates every one of these shapes is HBM-bound (1M x 512 x 512: 0.22 ms of matrix pipe at peak against
+// 2 GB = 0.33 ms of HBM traffic at the 6.3 TB/s a copy reaches), so the kernels are built around the byte stream:
+//   * row-panel form for nt / nn: one 512-thread workgroup owns ALL output columns of its rows (block tile 128 x 512,
+//     256 x 256, 256 x 128 ...), persistent over row tiles -- A is read from HBM exactly once, Y written once;
+//   * the weights are converted once per call into bf16 "planes" whose global layout IS the LDS image of a stage
+//     (64-byte rows of 32 k, 16-byte slots swizzled by (row >> 2) & 3: conflict-free ds_read_b128 fragments) and go
+//     global -> LDS with global_load_lds_dwordx4 (no registers, no ds_write);
+//   * three stage buffers: W copies run two stages ahead, the A rows three (registers), one barrier per stage with a
+//     counted vmcnt that leaves exactly the newest requests in flight;
+//   * the MFMA is issued with its operands swapped (D = W_tile . A_tile^T), so a lane ends up holding 4 consecutive output
+//     COLUMNS of one output row: two v_permlane32_swap make 16-byte pieces and the bf16 tile is stored without a trip
+//     through LDS (16 dwordx4 stores per lane and tile instead of 128 dword stores in the float32 kernels);
+//   * tn: both operands are contracted over rows, i.e. needed "8 consecutive rows of one column" -- they are staged
+//     row-major (coalesced 16-byte loads, 64-byte chunks swizzled by row & 3) and read with ds_read_b64_tr_b16.
+#include "b16_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using namespace ddmp;
+
+constexpr int kBK = 32;                       // contraction elements per stage (two MFMA k-steps)
+constexpr int kMaxK = 512;                    // widest contraction with a prologue (coefficient tables in LDS)
+
+__device__ __forceinline__ f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// element offset of (row, 16-byte slot) in a stage image of 32-element (64-byte) rows
+__device__ __host__ __forceinline__ int img_off(int row, int slot) { return row * kBK + ((slot ^ ((row >> 2) & 3)) << 3); }
+
+// W [M,K] (or its transpose) -> bf16 planes [stage][MP rows = output columns][32 contraction elements], zero padded
+__global__ __launch_bounds__(256) void w_planes_b16_kernel(const float* __restrict__ W, int64_t ldw, int MD, int KD,
+                                                           int transpose, int MP, __bf16* __restrict__ planes) {
+    const int ns = (KD + kBK - 1) / kBK;
+    const int total = ns * MP * kBK;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int kk = idx % kBK;
+        const int r = (idx / kBK) % MP;
+        const int st = idx / (kBK * MP);
+        const int c = st * kBK + kk;
+        float x = 0.f;
+        if (r < MD && c < KD) x = transpose ? W[(int64_t)c * ldw + r] : W[(int64_t)r * ldw + c];
+        planes[(int64_t)st * MP * kBK + img_off(r, kk >> 3) + (kk & 7)] = (__bf16)x;
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_barrier() {
+    // this wave's LDS writes (lgkmcnt) and all but its N youngest VMEM operations (register loads, global->LDS copies,
+    // stores: one in-order counter on gfx9) have completed before it arrives
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void lds_barrier() {                  // LDS traffic only; register loads stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Row-panel kernel.  8 waves as WR x WC, wave tile 64 rows x (32 NJ) columns, block tile (64 WR) x (32 NJ WC).
+//  PM: 0 = A as is; 1 = lrelu(A * scale[k] + shift[k]) (BatchNorm+LeakyReLU of the previous layer on the operand load).
+// ------------------------------------------------------------------------------------------------
+template <int WR, int WC, int NJ, int PM>
+__global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
+    const bf16_t* __restrict__ A, int64_t lda, const __bf16* __restrict__ Bp, bf16_t* __restrict__ Y, int64_t ldy,
+    int n_rows, int KD, int MD, const float* __restrict__ bias, const float* __restrict__ pscale,
+    const float* __restrict__ pshift, float slope, int n_row_tiles) {
+    static_assert(WR * WC == 8, "eight waves");
+    constexpr int BMR = 64 * WR, WN = 32 * NJ, MP = WN * WC;
+    constexpr int NA = BMR / 128;                                // 16-byte pieces of A per thread and stage
+    constexpr int kAStage = BMR * kBK, kBStage = MP * kBK;       // bf16 elements
+    constexpr int NCH = kBStage * 2 / 1024;                      // 1 KB chunks of a W stage
+    constexpr int NCW = NCH >= 8 ? NCH / 8 : 1;                  // copies per wave and stage (narrow outputs: duplicates)
+    constexpr int NV = NCW + NA;                                 // VMEM operations per wave and iteration
+    constexpr int NST = 4 * NJ;                                  // epilogue stores per lane
+    constexpr int NB = 3;
+    static_assert(NCH >= 8 ? NCH % 8 == 0 : 8 % NCH == 0, "every wave issues the same number of W copies");
+    static_assert(NV + NST <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NB * (kAStage + kBStage) * 2 + MP * 4 + (PM ? 2 * kMaxK * 4 : 0)];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bs = As + NB * kAStage;
+    float* s_bias = reinterpret_cast<float*>(Bs + NB * kBStage);
+    float* s_pro = s_bias + MP;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int ns = KD / kBK;
+    const int my_tiles = (n_row_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = my_tiles * ns;
+    const int last_t = (int)blockIdx.x + (my_tiles - 1) * (int)gridDim.x;
+
+    if (PM) {
+        for (int i = tid; i < KD; i += 512) {
+            s_pro[i] = pscale[i];
+            s_pro[kMaxK + i] = pshift[i];
+        }
+    }
+    for (int i = tid; i < MP; i += 512) s_bias[i] = (bias && i < MD) ? bias[i] : 0.f;
+    __syncthreads();
+
+    // ---- A stream: global (bf16) -> registers -> [prologue] -> LDS image
+    const int aslot = tid & 3, ar = tid >> 2;                    // (16-byte slot of the 64-byte stage row, row): 128 rows / pass
+    uint4 R[NB][NA];
+    const bf16_t* aptr[NA];
+    int lt = blockIdx.x, lk = 0;
+    auto a_tile = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int64_t row = min(t * BMR + p * 128 + ar, n_rows - 1);
+            aptr[p] = A + row * lda + aslot * 8;
+        }
+    };
+    a_tile(lt);
+    auto a_load = [&](uint4 (&r)[NA]) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) r[p] = *reinterpret_cast<const uint4*>(aptr[p] + lk);
+    };
+    auto a_advance = [&]() {
+        lk += kBK;
+        if (lk == KD) {
+            lk = 0;
+            lt = min(lt + (int)gridDim.x, last_t);               // past the end: harmless re-loads of the last tile
+            a_tile(lt);
+        }
+    };
+    int sk = 0;
+    auto a_store = [&](int buf, const uint4 (&r)[NA]) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            uint4 v = r[p];
+            if (PM == 1) {
+                float f[8], sc[8], sh[8];
+                bf_unpack8(v, f);
+                ld8f(&s_pro[sk + aslot * 8], sc);
+                ld8f(&s_pro[kMaxK + sk + aslot * 8], sh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = lrelu(fmaf(f[e], sc[e], sh[e]), slope);
+                v = bf_pack8(f);
+            }
+            *reinterpret_cast<uint4*>(As + buf * kAStage + img_off(p * 128 + ar, aslot)) = v;
+        }
+        sk += kBK;
+        sk = sk == KD ? 0 : sk;
+    };
+    // ---- W stream: planes -> LDS, 1 KB per wave instruction
+    const __bf16* bsrc = Bp + lane * 8;
+    int bk = 0;
+    auto b_copy = [&](int buf) {
+        __bf16* dst = Bs + buf * kBStage;
+#pragma unroll
+        for (int c0 = 0; c0 < NCW; ++c0) {
+            const int c = NCH >= 8 ? c0 * 8 + wave : wave % NCH;
+            __builtin_amdgcn_global_load_lds((const void*)(bsrc + c * 512), (void*)(dst + c * 512), 16, 0, 0);
+        }
+        ++bk;
+        const bool wrap = bk == ns;
+        bk = wrap ? 0 : bk;
+        bsrc = wrap ? Bp + lane * 8 : bsrc + kBStage;
+    };
+
+    // ---- MFMA side (operands swapped: the accumulator tile is D[m = output column][n = row])
+    f32x16 acc[2][NJ];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    const int swz = (l31 >> 2) & 3;                              // rows of a fragment: base (multiple of 32) + l31
+    int a_off[2], b_off[2];                                      // per k-step: slot 2 ks + lh
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_off[ks] = (wr * 64 + l31) * kBK + (((2 * ks + lh) ^ swz) << 3);
+        b_off[ks] = (wc * WN + l31) * kBK + (((2 * ks + lh) ^ swz) << 3);
+    }
+    bf16x8 af[2][2], bf[2][NJ];
+    auto rd = [&](int buf, int ks) {
+        const __bf16* as = As + buf * kAStage + a_off[ks];
+        const __bf16* bs = Bs + buf * kBStage + b_off[ks];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kBK);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * kBK);
+    };
+    auto mm = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma_b16(bf[ks][j], af[ks][i], acc[i][j]);
+    };
+    auto epilogue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = t * BMR + wr * 64 + i * 32 + l31;
+            bf16_t* yrow = Y + (int64_t)row * ldy;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int cb = wc * WN + j * 32;                 // this lane: columns cb + 8 g + 4 lh + (0..3), g = 0..3
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned w[2][2];                            // [group of the pair][dword]
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int g = 2 * gp + h;
+                        const float4 bv = *reinterpret_cast<const float4*>(&s_bias[cb + 8 * g + 4 * lh]);
+                        w[h][0] = bf_pack(acc[i][j][4 * g + 0] + bv.x, acc[i][j][4 * g + 1] + bv.y);
+                        w[h][1] = bf_pack(acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
+                    }
+                    // lanes >= 32 of group 2gp <-> lanes < 32 of group 2gp+1: afterwards lh = 0 holds columns
+                    // cb + 16 gp + (0..7), lh = 1 holds cb + 16 gp + (8..15), 16 contiguous bytes each
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    const int col = cb + 16 * gp + 8 * lh;
+                    if (row < n_rows && col < MD)
+                        *reinterpret_cast<uint4*>(yrow + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+    };
+
+    zero_acc();
+    int cur_t = blockIdx.x, cnt = 0;
+    bool stored = false;
+    // iteration g: stage g from buffer g % 3; A image of stage g+1 <- ring slot (g+1) % 3; W copy of stage g+2;
+    // ring slot g % 3 <- A loads of stage g+3
+    auto iteration = [&](int buf, int bufa, int bufw, uint4 (&rl)[NA], const uint4 (&rs)[NA]) {
+        rd(buf, 0);
+        rd(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0);
+        a_store(bufa, rs);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        b_copy(bufw);
+        asm volatile("" ::: "memory");                           // the A loads stay BEHIND the W copies in the VMEM stream
+        a_load(rl);
+        __builtin_amdgcn_sched_barrier(0);
+        a_advance();
+        stored = false;
+        if (++cnt == ns) {
+            cnt = 0;
+            epilogue(cur_t);
+            zero_acc();
+            cur_t += gridDim.x;
+            stored = true;
+        }
+    };
+    b_copy(0);
+    b_copy(1);
+    a_load(R[0]);
+    a_advance();
+    a_load(R[1]);
+    a_advance();
+    a_load(R[2]);
+    a_advance();
+    a_store(0, R[0]);
+    wait_barrier<0>();
+    for (int g = 0; g < G; g += 3) {
+        iteration(0, 1, 2, R[0], R[1]);
+        if (stored) wait_barrier<NV + NST>(); else wait_barrier<NV>();
+        if (g + 1 < G) iteration(1, 2, 0, R[1], R[2]);
+        if (stored) wait_barrier<NV + NST>(); else wait_barrier<NV>();
+        if (g + 2 < G) iteration(2, 0, 1, R[2], R[0]);
+        if (stored) wait_barrier<NV + NST>(); else wait_barrier<NV>();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no LDS copy outlives the workgroup
+}
+
+// contraction over 8 or 16 elements (the first layer: K = 16 | 8 input channels): plain VALU, 4 lanes per row,
+// 8 output columns each -- 0.5 GFMA at 1M rows, nothing for the matrix pipe to win
+template <int KD>
+__global__ __launch_bounds__(256) void gemm_rows_smallk_b16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const float* __restrict__ W, int64_t ldw,
+                                                                   bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int MD,
+                                                                   const float* __restrict__ bias) {
+    extern __shared__ float s_w[];                               // [MD][KD] + bias[MD]
+    for (int i = threadIdx.x; i < MD * KD; i += 256) s_w[i] = W[(int64_t)(i / KD) * ldw + (i % KD)];
+    for (int i = threadIdx.x; i < MD; i += 256) s_w[MD * KD + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int groups = MD / 8;
+    const int64_t total = (int64_t)n_rows * groups;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / groups;
+        const int c0 = (int)(idx % groups) * 8;
+        float a[KD];
+#pragma unroll
+        for (int q = 0; q < KD / 8; ++q) {
+            float t[8];
+            bf_unpack8(ld8b(A + row * lda + q * 8), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[q * 8 + e] = t[e];
+        }
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float s = s_w[MD * KD + c0 + c];
+#pragma unroll
+            for (int k = 0; k < KD; ++k) s = fmaf(a[k], s_w[(c0 + c) * KD + k], s);
+            o[c] = s;
+        }
+        st8b(Y + row * ldy + c0, bf_pack8(o));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  wgrad:  partial[split][m][k] = sum_{rows of the split} G[row][m] * f(Z[row][k])        (float32)
+//  One workgroup = one 256 x 256 output panel x one row range; 8 waves as 4 (m) x 2 (k), each 64 x 128.
+//  Both operands are staged row-major [32 rows][256 columns] (16-byte coalesced loads -> ds_write_b128; the 64-byte
+//  chunk c of row r sits at chunk c ^ (r & 3)) and the MFMA fragments -- 8 consecutive rows of one column -- come out
+//  of ds_read_b64_tr_b16 (two per fragment).  Two LDS buffers, two register slots: the loads of stage s+3 are issued in
+//  iteration s and consumed in iteration s+2.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTT = 256;                                          // panel edge
+__device__ __forceinline__ int tn_off(int row, int col) {         // element offset in a [32][256] stage image
+    return row * kTT + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31));
+}
+
+template <bool ZPRO>
+__global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
+    const bf16_t* __restrict__ G, int64_t ldg, const bf16_t* __restrict__ Z, int64_t ldz, float* __restrict__ out,
+    int64_t ld_out, int64_t split_stride, int n_rows, int M, int K, int rows_per_split, int n_tiles_m, int n_tiles_k,
+    int n_splits, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope) {
+    constexpr int kStage = kBK * kTT;                            // elements of one operand stage
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][kStage];
+    __shared__ __attribute__((aligned(16))) __bf16 Zs[2][kStage];
+
+    const int n_tiles = n_tiles_m * n_tiles_k;
+    const int xcd = blockIdx.x & (kXcd - 1), local = blockIdx.x >> 3;
+    const int tile = local % n_tiles;
+    const int split = (local / n_tiles) * kXcd + xcd;
+    if (split >= n_splits) return;
+    const int tm0 = (tile / n_tiles_k) * kTT, tk0 = (tile % n_tiles_k) * kTT;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_rows, r_begin + rows_per_split);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;                     // 4 x 2 waves: 64 (m) x 128 (k) each
+    const int l31 = lane & 31, lh = lane >> 5;
+    // staging role: 32 threads per row (8 columns = 16 bytes each), 16 rows per pass, 2 passes per operand and stage
+    const int sc8 = tid & 31, sr = tid >> 5;
+    const int gcol = tm0 + sc8 * 8, zcol = tk0 + sc8 * 8;
+    const bool g_on = gcol < M, z_on = zcol < K;                 // M, K % 8 == 0: a piece is all in or all out
+    float pa[8], pb[8];
+    if (ZPRO && z_on) {
+        ld8f(pscale + zcol, pa);
+        ld8f(pshift + zcol, pb);
+    }
+    uint4 rg[2][2], rz[2][2];                                    // [slot][pass]
+    auto load = [&](int sl, int r0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t row = min(r0 + p * 16 + sr, r_end - 1);
+            rg[sl][p] = g_on ? ld8b(G + row * ldg + gcol) : make_uint4(0, 0, 0, 0);
+            rz[sl][p] = z_on ? ld8b(Z + row * ldz + zcol) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store = [&](int buf, int sl, int r0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = p * 16 + sr;
+            uint4 g = rg[sl][p], z = rz[sl][p];
+            if (r0 + r >= r_end) g = make_uint4(0, 0, 0, 0);     // rows beyond the split contribute nothing
+            if (ZPRO) {
+                float f[8];
+                bf_unpack8(z, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = lrelu(fmaf(f[e], pa[e], pb[e]), slope);
+                z = z_on ? bf_pack8(f) : make_uint4(0, 0, 0, 0);
+            }
+            *reinterpret_cast<uint4*>(&Gs[buf][tn_off(r, sc8 * 8)]) = g;
+            *reinterpret_cast<uint4*>(&Zs[buf][tn_off(r, sc8 * 8)]) = z;
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // transpose reads: lane L = lane & 15 of a 16-lane group supplies the address of 4 consecutive columns of row
+    // (L >> 2) and receives column (lane & 31) of the tile, rows 0..3 of the 4-row block
+    const int L = lane & 15, gi = (lane >> 4) & 1;
+    const bool wave_on = (tm0 + wr * 64 < M) && (tk0 + wc * 128 < K);
+    auto frag = [&](const __bf16* img, int cbase, int ks) -> bf16x8 {
+        const int nb = ks * 16 + lh * 8;
+        const int col = cbase + 16 * gi + 4 * (L & 3);
+        typedef __attribute__((address_space(3))) bf16x4* lp;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(img + tn_off(nb + (L >> 2), col)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(img + tn_off(nb + 4 + (L >> 2), col)));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+    };
+    auto compute = [&](int buf) {
+        if (!wave_on) return;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag(Gs[buf], wr * 64 + i * 32, ks);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag(Zs[buf], wc * 128 + j * 32, ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_b16(af[i], bf[j], acc[i][j]);
+        }
+    };
+
+    const int ns = (r_end - r_begin + kBK - 1) / kBK;
+    if (ns > 0) {
+        load(0, r_begin);
+        load(1, r_begin + kBK);
+        store(0, 0, r_begin);
+        load(0, r_begin + 2 * kBK);
+    }
+    lds_barrier();
+    // iteration s (LDS buffer s & 1): slot (s+1) & 1 holds stage s+1; it is stored into the other buffer and refilled with
+    // stage s+3
+#pragma unroll 1
+    for (int s = 0; s < ns; s += 2) {
+        const int r1 = r_begin + (s + 1) * kBK;
+        compute(0);
+        store(1, 1, r1);
+        load(1, r1 + 2 * kBK);
+        lds_barrier();
+        if (s + 1 < ns) {
+            compute(1);
+            store(0, 0, r1 + kBK);
+            load(0, r1 + 3 * kBK);
+        }
+        lds_barrier();
+    }
+
+    if (!wave_on) return;
+    float* o = out + (int64_t)split * split_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = tk0 + wc * 128 + j * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tm0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) o[(int64_t)m * ld_out + k] = acc[i][j][r];
+            }
+    }
+}
+
+// dW = sum over splits of the partial panels (float64 accumulation); 4 splits x 4 elements in flight per thread
+__global__ __launch_bounds__(256) void reduce_splits_b16_kernel(const float* __restrict__ part, int64_t split_stride,
+                                                                int n_splits, float* __restrict__ dW, int64_t lddw, int M,
+                                                                int K) {
+    const int q = blockIdx.x * 256 + threadIdx.x;                // float4 index (K % 4 == 0)
+    if (q * 4 >= M * K) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = 0;
+    for (; i + 3 < n_splits; i += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(i + u) * split_stride + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+    }
+    for (; i < n_splits; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)i * split_stride + 4 * q);
+        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+    const int idx = 4 * q, m = idx / K, k = idx % K;
+    float* o = dW + (int64_t)m * lddw + k;
+    o[0] = (float)s0; o[1] = (float)s1; o[2] = (float)s2; o[3] = (float)s3;
+}
+
+struct TnPlanB {
+    int n_tiles_m, n_tiles_k, n_splits, rows_per_split;
+};
+TnPlanB tn_plan_b16(int64_t n_rows, int M, int K) {
+    TnPlanB p;
+    p.n_tiles_m = (int)cdiv(M, kTT);
+    p.n_tiles_k = (int)cdiv(K, kTT);
+    const int tiles = p.n_tiles_m * p.n_tiles_k;
+    // one 512-thread workgroup per CU (two where the tiles are few); >= 256 rows per split; multiple of 8 splits
+    int64_t want = std::max<int64_t>(1, (2 * kCu) / tiles);
+    want = std::min<int64_t>(want, cdiv(n_rows, 256));
+    want = std::max<int64_t>(kXcd, (want / kXcd) * kXcd);
+    int64_t rps = cdiv(cdiv(n_rows, want), kBK) * kBK;
+    p.rows_per_split = (int)rps;
+    p.n_splits = (int)cdiv(n_rows, rps);
+    return p;
+}
+
+int device_cus_b16() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = kCu;
+    }
+    return cus;
+}
+
+int planes_mp(int MD) { return MD > 256 ? 512 : MD > 128 ? 256 : MD > 64 ? 128 : MD > 32 ? 64 : 32; }
+
+template <int WR, int WC, int NJ>
+void launch_rows(const bf16_t* A, int64_t lda, const __bf16* planes, bf16_t* Y, int64_t ldy, int64_t n_rows, int KD, int MD,
+                 const float* bias, const float* ps, const float* psh, float slope, hipStream_t st) {
+    constexpr int BMR = 64 * WR;
+    const int n_tiles = (int)cdiv(n_rows, BMR);
+    const int grid = std::min(n_tiles, device_cus_b16());
+    if (ps)
+        hipLaunchKernelGGL((gemm_rows_b16_kernel<WR, WC, NJ, 1>), dim3(grid), dim3(512), 0, st, A, lda, planes, Y, ldy,
+                           (int)n_rows, KD, MD, bias, ps, psh, slope, n_tiles);
+    else
+        hipLaunchKernelGGL((gemm_rows_b16_kernel<WR, WC, NJ, 0>), dim3(grid), dim3(512), 0, st, A, lda, planes, Y, ldy,
+                           (int)n_rows, KD, MD, bias, ps, psh, slope, n_tiles);
+}
+
+// Y[n, MD] = f(A[n, KD]) . B  with B[k][m] = transpose ? W[k][m] : W[m][k]
+int gemm_rows_b16(const bf16_t* A, int64_t lda, const float* W, int64_t ldw, int transpose, bf16_t* Y, int64_t ldy,
+                  int64_t n_rows, int KD, int MD, const float* bias, const float* ps, const float* psh, float slope,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+    ARG_TRY(A && W && Y && n_rows > 0 && n_rows < INT32_MAX && KD > 0 && MD > 0 && MD <= 512 && MD % 8 == 0 && KD % 8 == 0);
+    ARG_TRY(lda >= KD && ldy >= MD && lda % 8 == 0 && ldy % 8 == 0 && b16_aligned(A) && b16_aligned(Y));
+    ARG_TRY((ps == nullptr) == (psh == nullptr));
+    if (KD < kBK) {                                              // first layer
+        ARG_TRY(!transpose && !ps && (KD == 8 || KD == 16));
+        const int grid = (int)std::min<int64_t>(cdiv(n_rows * (MD / 8), 256), 256 * 8);
+        const size_t sh = (size_t)(MD * KD + MD) * sizeof(float);
+        if (KD == 8)
+            hipLaunchKernelGGL((gemm_rows_smallk_b16_kernel<8>), dim3(grid), dim3(256), sh, st, A, lda, W, ldw, Y, ldy, (int)n_rows, MD, bias);
+        else
+            hipLaunchKernelGGL((gemm_rows_smallk_b16_kernel<16>), dim3(grid), dim3(256), sh, st, A, lda, W, ldw, Y, ldy, (int)n_rows, MD, bias);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
+    ARG_TRY(KD % kBK == 0 && (!ps || KD <= kMaxK));
+    const int MP = planes_mp(MD);
+    const size_t need = (size_t)KD * MP * sizeof(uint16_t);
+    if (!ws || ws_bytes < need || !b16_aligned(ws)) return DDMP_EWORKSPACE;
+    __bf16* planes = (__bf16*)ws;
+    hipLaunchKernelGGL(w_planes_b16_kernel, dim3((unsigned)std::min<int64_t>(cdiv((int64_t)KD * MP, 256), 1024)), dim3(256), 0,
+                       st, W, ldw, MD, KD, transpose, MP, planes);
+    LAUNCH_TRY();
+    if (MP == 512) launch_rows<2, 4, 4>(A, lda, planes, Y, ldy, n_rows, KD, MD, bias, ps, psh, slope, st);
+    else if (MP == 256) launch_rows<4, 2, 4>(A, lda, planes, Y, ldy, n_rows, KD, MD, bias, ps, psh, slope, st);
+    else if (MP == 128) launch_rows<4, 2, 2>(A, lda, planes, Y, ldy, n_rows, KD, MD, bias, ps, psh, slope, st);
+    else if (MP == 64) launch_rows<4, 2, 1>(A, lda, planes, Y, ldy, n_rows, KD, MD, bias, ps, psh, slope, st);
+    else launch_rows<8, 1, 1>(A, lda, planes, Y, ldy, n_rows, KD, MD, bias, ps, psh, slope, st);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ddmp_gemm_rows_bf16_workspace_bytes(int K, int M) {
+    if (K <= 0 || M <= 0) return 0;
+    const int kp = (int)cdiv(K, kBK) * kBK, mp = (int)cdiv(M, kBK) * kBK;
+    return (size_t)std::max(kp, mp) * 512 * sizeof(uint16_t);
+}
+
+extern "C" int ddmp_gemm_nt_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                                 int64_t n_rows, int K, int M, const float* bias, const float* pro_scale,
+                                 const float* pro_shift, float slope, void* workspace, size_t workspace_bytes,
+                                 ddmp_stream stream) {
+    ARG_TRY(ldw >= K);
+    return gemm_rows_b16(A, lda, W, ldw, 0, Y, ldy, n_rows, K, M, bias, pro_scale, pro_shift, slope, workspace,
+                         workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int ddmp_gemm_nn_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                                 int64_t n_rows, int M, int K, void* workspace, size_t workspace_bytes,
+                                 ddmp_stream stream) {
+    ARG_TRY(ldw >= K);
+    return gemm_rows_b16(A, lda, W, ldw, 1, Y, ldy, n_rows, M, K, nullptr, nullptr, nullptr, 0.f, workspace,
+                         workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t ddmp_gemm_tn_bf16_workspace_bytes(int64_t n_rows, int M, int K) {
+    if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
+    const TnPlanB p = tn_plan_b16(n_rows, M, K);
+    return (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+}
+
+extern "C" int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t ldz, float* dW, int64_t lddw,
+                                 int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift,
+                                 float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream) {
+    ARG_TRY(G && Z && dW && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0 && M % 8 == 0 && K % 8 == 0);
+    ARG_TRY(ldg >= M && ldz >= K && lddw >= K && ldg % 8 == 0 && ldz % 8 == 0 && b16_aligned(G) && b16_aligned(Z));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(!pro_scale || (b16_aligned(pro_scale) && b16_aligned(pro_shift)));
+    hipStream_t st = (hipStream_t)stream;
+    const TnPlanB p = tn_plan_b16(n_rows, M, K);
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    if (!workspace || workspace_bytes < need || !b16_aligned(workspace)) return DDMP_EWORKSPACE;
+    float* part = (float*)workspace;
+    const int64_t sstride = (int64_t)M * K;
+    const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(512);
+    if (pro_scale)
+        hipLaunchKernelGGL((gemm_tn_b16_kernel<true>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
+                           (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);
+    else
+        hipLaunchKernelGGL((gemm_tn_b16_kernel<false>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
+                           (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(reduce_splits_b16_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part, sstride,
+                       p.n_splits, dW, lddw, M, K);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}

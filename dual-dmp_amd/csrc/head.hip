@@ -7,7 +7,7 @@
 // One thread per node; weights are wave-uniform scalar loads.  Backward recomputes the forward from
 // the saved conv12 output, writes dZ [n,32] and reduces the four parameter gradients through LDS
 // tiles of 256 nodes (no atomics; per-block partials + a final reduction -> deterministic).
-#include "ddmp_common.h"
+#include "b16_common.h"
 
 #include <algorithm>
 
@@ -22,17 +22,37 @@ struct HeadW {
     const float *W1, *b1, *W2, *b2;
 };
 
-__device__ __forceinline__ void head_forward_row(const float* __restrict__ yrow, const float* __restrict__ scale,
-                                                 const float* __restrict__ shift, float slope, const HeadW& w,
-                                                 float (&z)[H0], float (&tp)[H1], float (&u)[H2]) {
+// the conv12 output row: float32 or bfloat16 features (b16_common.h)
+__device__ __forceinline__ void load_row32(const float* __restrict__ yrow, float (&y)[H0]) {
 #pragma unroll
     for (int q = 0; q < H0 / 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(yrow + q * 4);
-        z[q * 4 + 0] = lrelu(fmaf(v.x, scale[q * 4 + 0], shift[q * 4 + 0]), slope);
-        z[q * 4 + 1] = lrelu(fmaf(v.y, scale[q * 4 + 1], shift[q * 4 + 1]), slope);
-        z[q * 4 + 2] = lrelu(fmaf(v.z, scale[q * 4 + 2], shift[q * 4 + 2]), slope);
-        z[q * 4 + 3] = lrelu(fmaf(v.w, scale[q * 4 + 3], shift[q * 4 + 3]), slope);
+        y[q * 4 + 0] = v.x; y[q * 4 + 1] = v.y; y[q * 4 + 2] = v.z; y[q * 4 + 3] = v.w;
     }
+}
+__device__ __forceinline__ void load_row32(const bf16_t* __restrict__ yrow, float (&y)[H0]) {
+#pragma unroll
+    for (int q = 0; q < H0 / 8; ++q) {
+        float t[8];
+        bf_unpack8(ld8b(yrow + q * 8), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[q * 8 + e] = t[e];
+    }
+}
+__device__ __forceinline__ void store_quad(float* p, const float (&d)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+}
+__device__ __forceinline__ void store_quad(bf16_t* p, const float (&d)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(bf_pack(d[0], d[1]), bf_pack(d[2], d[3]));
+}
+
+template <typename T>
+__device__ __forceinline__ void head_forward_row(const T* __restrict__ yrow, const float* __restrict__ scale,
+                                                 const float* __restrict__ shift, float slope, const HeadW& w,
+                                                 float (&z)[H0], float (&tp)[H1], float (&u)[H2]) {
+    load_row32(yrow, z);
+#pragma unroll
+    for (int j = 0; j < H0; ++j) z[j] = lrelu(fmaf(z[j], scale[j], shift[j]), slope);
 #pragma unroll
     for (int i = 0; i < H1; ++i) {
         float s = w.b1[i];
@@ -49,7 +69,8 @@ __device__ __forceinline__ void head_forward_row(const float* __restrict__ yrow,
     }
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ Y, int64_t ldy, int n_rows,
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ Y, int64_t ldy, int n_rows,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float slope, HeadW w,
                                                        int kind, const float* __restrict__ x_pos,
@@ -74,11 +95,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ Y, int64_t ldy, int n_rows,
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ Y, int64_t ldy, int n_rows,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float slope, HeadW w,
                                                        int kind, const float* __restrict__ dout,
-                                                       float* __restrict__ dZ, int64_t lddz,
+                                                       T* __restrict__ dZ, int64_t lddz,
                                                        float* __restrict__ partial /*[grid][kNPar]*/) {
     __shared__ float zs[256][H0 + 1];
     __shared__ float dtps[256][H1 + 1];
@@ -116,7 +138,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                 for (int o = 0; o < H2; ++o) s = fmaf(w.W2[o * H1 + i], du[o], s);
                 dtp[i] = s * lrelu_grad(tp[i], slope);
             }
-            float* dz = dZ + (int64_t)row * lddz;
+            T* dz = dZ + (int64_t)row * lddz;
 #pragma unroll
             for (int q = 0; q < H0 / 4; ++q) {
                 float d[4];
@@ -127,7 +149,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                     for (int i = 0; i < H1; ++i) s = fmaf(w.W1[i * H0 + q * 4 + e], dtp[i], s);
                     d[e] = s;
                 }
-                *reinterpret_cast<float4*>(dz + q * 4) = make_float4(d[0], d[1], d[2], d[3]);
+                store_quad(dz + q * 4, d);
             }
         } else {
 #pragma unroll
@@ -202,7 +224,7 @@ extern "C" int ddmp_head_fwd_f32(const float* Y, int64_t ldy, int64_t n_rows, co
     ARG_TRY(ldy >= H0 && ldy % 4 == 0 && (kind == 0 || kind == 1) && (kind == 1 || x_pos));
     const int grid = (int)std::min<int64_t>(cdiv(n_rows, 256), 256 * 8);
     HeadW w{W1, b1, W2, b2};
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
+    hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
                        shift, slope, w, kind, x_pos, out);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -224,7 +246,41 @@ extern "C" int ddmp_head_bwd_f32(const float* Y, int64_t ldy, int64_t n_rows, co
     const int nblk = head_bwd_blocks(n_rows);
     if (!ws || ws_bytes < (size_t)nblk * kNPar * sizeof(float)) return DDMP_EWORKSPACE;
     HeadW w{W1, b1, W2, b2};
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
+    hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
+                       shift, slope, w, kind, dout, dZ, lddz, (float*)ws);
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)cdiv(kNPar, 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, nblk, dW1, db1, dW2, db2);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+
+// ---- bfloat16 features: Y (conv12 output) and dZ are bf16 [n,32]; out / dout / parameters stay float32
+extern "C" int ddmp_head_fwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                                  float slope, const float* W1, const float* b1, const float* W2, const float* b2,
+                                  int kind, const float* x_pos, float* out, ddmp_stream stream) {
+    ARG_TRY(Y && scale && shift && W1 && b1 && W2 && b2 && out && n_rows > 0 && n_rows < INT32_MAX);
+    ARG_TRY(ldy >= H0 && ldy % 8 == 0 && b16_aligned(Y) && (kind == 0 || kind == 1) && (kind == 1 || x_pos));
+    const int grid = (int)std::min<int64_t>(cdiv(n_rows, 256), 256 * 8);
+    HeadW w{W1, b1, W2, b2};
+    hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
+                       shift, slope, w, kind, x_pos, out);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_head_bwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                                  float slope, const float* W1, const float* b1, const float* W2, const float* b2,
+                                  int kind, const float* dout, uint16_t* dZ, int64_t lddz, float* dW1, float* db1,
+                                  float* dW2, float* db2, void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(Y && scale && shift && W1 && b1 && W2 && b2 && dout && dZ && dW1 && db1 && dW2 && db2);
+    ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && ldy >= H0 && ldy % 8 == 0 && lddz >= H0 && lddz % 8 == 0);
+    ARG_TRY((kind == 0 || kind == 1) && b16_aligned(Y) && b16_aligned(dZ));
+    const int nblk = head_bwd_blocks(n_rows);
+    if (!ws || ws_bytes < (size_t)nblk * kNPar * sizeof(float)) return DDMP_EWORKSPACE;
+    HeadW w{W1, b1, W2, b2};
+    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, Y, ldy, (int)n_rows, scale,
                        shift, slope, w, kind, dout, dZ, lddz, (float*)ws);
     LAUNCH_TRY();
     hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)cdiv(kNPar, 32)), dim3(256), 0, (hipStream_t)stream,

@@ -1,0 +1,252 @@
+// GCN aggregation on bfloat16 features:  Y[i,:] = bf16( dinv[i] * sum_{e in row i} dinv[col e] * f(X[col e,:]) (+ bias) )
+//
+// The bf16-feature form of spmm.hip's slab kernel (GCNConv.propagate of PyG 2.2.0, util/networks.py:51-62 of the
+// reference).  Same work layout -- a workgroup owns 64 consecutive rows, its CSR slice and the dinv[col] weights are
+// staged once in LDS, the rows are walked one 128-byte slab at a time, XCD-aware chunk mapping, no atomics -- but a lane
+// now carries 8 channels (16 bytes of bf16), so a 128-byte slab is 64 channels and a gathered line feeds twice the
+// channels of the float32 kernel.  Gathered elements are unpacked to float32, the prologue / BatchNorm-backward rebuild
+// and the accumulation run in float32, the result is rounded to nearest-even once.
+// Algorithmic bytes per call: 2*N*C*2 + 4*nnz + 4*(N+1) + 4*N  (SURVEY.md §8d with s = 2).
+#include "b16_common.h"
+
+#include <algorithm>
+
+namespace {
+
+using namespace ddmp;
+
+constexpr int kRB = 64;
+constexpr int kMaxE = kRB * 16;
+
+struct BnRedB {                    // see BnRed in spmm.hip
+    const bf16_t* Yp;
+    int64_t ldyp;
+    const float *scale, *shift, *mean, *rstd;
+    float* part;
+};
+struct BnBwdGatherB {              // see BnBwdGather in spmm.hip
+    const bf16_t* Yb;
+    int64_t ldyb;
+    const float *c1, *c0;
+};
+
+// LANES lanes x 8 channels per row and slab (LANES = 8: 128-byte slabs; 4 | 2 | 1 for C = 32 | 16 | 8)
+template <int LANES, int U, bool PRO, bool RED, bool BWD>
+__global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
+    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
+    float slope, int chunks_per_xcd, int n_chunks, BnRedB red, BnBwdGatherB bwd) {
+    static_assert(!BWD || (PRO && !RED), "BWD: the coefficients a, b come as the prologue's");
+    constexpr int CS = LANES * 8;
+    constexpr int RPW = 64 / LANES;
+    constexpr int RPB = 4 * RPW;
+    __shared__ int s_rowptr[kRB + 1];
+    __shared__ int s_col[kMaxE];
+    __shared__ float s_w[kMaxE];
+
+    const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
+    if (chunk >= n_chunks) return;
+    const int r0 = chunk * kRB;
+    const int nr = min(kRB, n_rows - r0);
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
+    __syncthreads();
+    const int e0 = s_rowptr[0];
+    const int ne = s_rowptr[nr] - e0;
+    const bool staged = ne <= kMaxE;
+    if (staged) {
+        for (int t = tid; t < ne; t += 256) {
+            const int c = col[e0 + t];
+            s_col[t] = c;
+            s_w[t] = dinv[c];
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / LANES, sl = lane % LANES;
+    for (int c0 = 0; c0 < C; c0 += CS) {
+        const int off = c0 + sl * 8;
+        float pa[8], pb[8], bs[8], k1[8], k0[8];
+        float ra[8], rb[8], rmu[8], rrs[8], q0[8], q1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pa[j] = 1.f; pb[j] = 0.f; bs[j] = 0.f; k1[j] = 0.f; k0[j] = 0.f;
+            q0[j] = 0.f; q1[j] = 0.f;
+        }
+        if (PRO) {
+            ld8f(pscale + off, pa);
+            ld8f(pshift + off, pb);
+        }
+        if (bias) ld8f(bias + off, bs);
+        if (BWD) {
+            ld8f(bwd.c1 + off, k1);
+            ld8f(bwd.c0 + off, k0);
+        }
+        if (RED) {
+            ld8f(red.scale + off, ra);
+            ld8f(red.shift + off, rb);
+            ld8f(red.mean + off, rmu);
+            ld8f(red.rstd + off, rrs);
+        }
+        const bf16_t* xc = X + off;
+        const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
+        for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
+            int es = s_rowptr[lr] - e0;
+            const int ee = s_rowptr[lr + 1] - e0;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            while (es < ee) {
+                int cj[U];
+                float wj[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int ek = min(es + k, ee - 1);
+                    if (staged) {
+                        cj[k] = s_col[ek];
+                        wj[k] = s_w[ek];
+                    } else {
+                        cj[k] = col[e0 + ek];
+                        wj[k] = dinv[cj[k]];
+                    }
+                    if (es + k >= ee) wj[k] = 0.f;
+                }
+                uint4 v[U], vy[BWD ? U : 1];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    v[k] = ld8b(xc + (int64_t)cj[k] * ldx);
+                    if (BWD) vy[BWD ? k : 0] = ld8b(yc + (int64_t)cj[k] * bwd.ldyb);
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    float t[8];
+                    bf_unpack8(v[k], t);
+                    if (BWD) {
+                        float y[8];
+                        bf_unpack8(vy[BWD ? k : 0], y);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            t[j] = fmaf(pa[j], t[j] * lrelu_grad(fmaf(y[j], pa[j], pb[j]), slope), fmaf(k1[j], y[j], k0[j]));
+                    } else if (PRO) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t[j] = lrelu(fmaf(t[j], pa[j], pb[j]), slope);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(wj[k], t[j], acc[j]);
+                }
+                es += U;
+            }
+            const int row = r0 + lr;
+            const float di = dinv[row];
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf(acc[j], di, bs[j]);
+            const uint4 ob = bf_pack8(o);
+            nt_st8b(Y + (int64_t)row * ldy + off, ob);
+            if (RED) {                                           // on the values as stored (rounded)
+                float y[8];
+                bf_unpack8(ob, o);
+                bf_unpack8(ld8b(red.Yp + (int64_t)row * red.ldyp + off), y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = o[j] * lrelu_grad(fmaf(y[j], ra[j], rb[j]), slope);
+                    q0[j] += g;
+                    q1[j] = fmaf(g, (y[j] - rmu[j]) * rrs[j], q1[j]);
+                }
+            }
+        }
+        if (RED) {                                               // per wave and chunk: one partial per channel
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int o = LANES; o < 64; o <<= 1) {
+                    q0[j] += __shfl_xor(q0[j], o, 64);
+                    q1[j] += __shfl_xor(q1[j], o, 64);
+                }
+            if (grp == 0) {
+                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
+                *reinterpret_cast<float4*>(pp) = make_float4(q0[0], q0[1], q0[2], q0[3]);
+                *reinterpret_cast<float4*>(pp + 4) = make_float4(q0[4], q0[5], q0[6], q0[7]);
+                *reinterpret_cast<float4*>(pp + C) = make_float4(q1[0], q1[1], q1[2], q1[3]);
+                *reinterpret_cast<float4*>(pp + C + 4) = make_float4(q1[4], q1[5], q1[6], q1[7]);
+            }
+        }
+    }
+}
+
+#include "fpartials.inc"
+
+template <int LANES, bool PRO, bool RED, bool BWD>
+int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
+               const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red, BnBwdGatherB bwd) {
+    const int n = (int)g->n_rows;
+    const int n_chunks = (int)cdiv(n, kRB);
+    const int cpx = (int)cdiv(n_chunks, kXcd);
+    hipLaunchKernelGGL((spmm_slab_b16_kernel<LANES, 4, PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
+                       g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red, bwd);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+template <bool PRO, bool RED, bool BWD>
+int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
+                 const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red = BnRedB(),
+                 BnBwdGatherB bwd = BnBwdGatherB()) {
+    if (C % 64 == 0) return launch_b16<8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    if (C % 32 == 0) return launch_b16<4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    if (C % 16 == 0) return launch_b16<2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    return launch_b16<1, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+}
+
+bool shape_ok(const void* X, int64_t ldx, const void* Y, int64_t ldy, int C) {
+    return C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C && b16_aligned(X) && b16_aligned(Y);
+}
+bool coef_ok(const float* p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ddmp_spmm_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                              const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+                              ddmp_stream stream) {
+    ARG_TRY(g && X && Y && X != Y && shape_ok(X, ldx, Y, ldy, C));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(coef_ok(bias) && coef_ok(pro_scale) && coef_ok(pro_shift));
+    hipStream_t st = (hipStream_t)stream;
+    if (pro_scale) return dispatch_b16<true, false, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
+    return dispatch_b16<false, false, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st);
+}
+
+extern "C" size_t ddmp_spmm_bnred_bf16_workspace_bytes(int64_t n_rows, int C) {
+    if (n_rows <= 0 || C <= 0) return 0;
+    return (size_t)ddmp::cdiv(n_rows, kRB) * 4 * 2 * (size_t)C * sizeof(float) + 256 + fpartials_mid_bytes(C);
+}
+
+extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                                    const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift,
+                                    const float* mean, const float* rstd, float slope, double* sums2, void* ws,
+                                    size_t ws_bytes, ddmp_stream stream) {
+    ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && X != Y && shape_ok(X, ldx, Y, ldy, C));
+    ARG_TRY(ldyp >= C && ldyp % 8 == 0 && b16_aligned(Yp) && b16_aligned(ws));
+    ARG_TRY(coef_ok(scale) && coef_ok(shift) && coef_ok(mean) && coef_ok(rstd));
+    if (ws_bytes < ddmp_spmm_bnred_bf16_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_chunks = (int)cdiv(g->n_rows, kRB);
+    BnRedB red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
+    int rc = dispatch_b16<false, true, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
+    if (rc != DDMP_OK) return rc;
+    const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
+    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_spmm_bnbwd_bf16(const ddmp_graph* g, const uint16_t* dZ, int64_t lddz, const uint16_t* Yb,
+                                    int64_t ldyb, uint16_t* out, int64_t ld_out, int C, const float* a, const float* b,
+                                    const float* c1, const float* c0, float slope, ddmp_stream stream) {
+    ARG_TRY(g && dZ && Yb && out && a && b && c1 && c0 && dZ != out && Yb != out && shape_ok(dZ, lddz, out, ld_out, C));
+    ARG_TRY(ldyb >= C && ldyb % 8 == 0 && b16_aligned(Yb) && coef_ok(a) && coef_ok(b) && coef_ok(c1) && coef_ok(c0));
+    BnBwdGatherB bwd{Yb, ldyb, c1, c0};
+    return dispatch_b16<true, false, true>(g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRedB(), bwd);
+}

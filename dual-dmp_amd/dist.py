@@ -322,9 +322,11 @@ class DistributedTrainer:
         vg = self.ops.Graph.from_csr_host(sd.vplan.rowptr, sd.vplan.col, sd.vplan.dinv, sd.vplan.n_cols)
         fg = self.ops.Graph.from_csr_host(sd.fplan.rowptr, sd.fplan.col, sd.fplan.dinv, sd.fplan.n_cols)
         self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
-                              comm=GraphComm(backend, sd.vplan, device), n_total=sd.V)
+                              comm=GraphComm(backend, sd.vplan, device), n_total=sd.V,
+                              dtype=getattr(posnet, "feature_dtype", torch.float32))
         self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
-                              comm=GraphComm(backend, sd.fplan, device), n_total=sd.F)
+                              comm=GraphComm(backend, sd.fplan, device), n_total=sd.F,
+                              dtype=getattr(normnet, "feature_dtype", torch.float32))
         posnet._engine, normnet._engine = self.peng, self.neng
         self.owned_v = torch.from_numpy(sd.vplan.owned).to(device)
         self.owned_f = torch.from_numpy(sd.fplan.owned).to(device)

@@ -153,10 +153,18 @@ class GcnEngine:
 
     def __init__(self, graph: ops.Graph, widths: List[int], kind: int, x0: torch.Tensor,
                  x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None,
-                 perm: Optional[torch.Tensor] = None):
+                 perm: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32):
         """``perm`` (int64 [n_rows], new -> old): the engine works on nodes relabelled for gather locality
         (``graph`` and ``x0``/``x_pos`` must already be in the NEW numbering); :meth:`forward` returns and
-        :meth:`backward` accepts rows in the caller's ORIGINAL numbering."""
+        :meth:`backward` accepts rows in the caller's ORIGINAL numbering.
+
+        ``dtype``: feature dtype in HBM.  ``torch.bfloat16`` = the bf16-feature mode (BASELINE.json configs[1]): the
+        static input, every conv output ``Y_l`` / aggregate ``P_l`` kept for backward and every activation gradient
+        are bfloat16; parameters, BatchNorm coefficients, the [n,3] result and everything the optimizer touches
+        stay float32 (arithmetic: float32 accumulation, float64 statistics, one bf16 MFMA product per step)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("feature dtype must be torch.float32 or torch.bfloat16")
+        self.dtype = dtype
         self.g = graph
         self.kind = kind
         self.layout = ArenaLayout(widths)
@@ -168,15 +176,15 @@ class GcnEngine:
         L = self.layout
         # static input, padded to a multiple of 4 channels (z2 has 7 columns)
         assert x0.shape[0] >= self.n_cols and x0.shape[1] == L.cin[0]
-        self.x0 = torch.zeros((self.n_cols, L.cin_p[0]), dtype=torch.float32, device=dev)
-        self.x0[:, :L.cin[0]] = x0[:self.n_cols].to(torch.float32)
+        self.x0 = torch.zeros((self.n_cols, L.cin_p[0]), dtype=dtype, device=dev)
+        self.x0[:, :L.cin[0]] = x0[:self.n_cols].to(dtype)
         self.x_pos = None if x_pos is None else x_pos[:self.n_rows].contiguous().to(torch.float32)
         # aggregate on the narrower side; equal widths aggregate first too: then dY feeds only GEMMs and, where the
         # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
         self.agg_first = [L.cin_p[l] <= L.cout[l] for l in range(12)]
         supported = getattr(ops, "gemm_bnbwd_supported", None)
-        self.fuse_bnbwd = [bool(supported) and l > 0 and self.agg_first[l] and supported(L.cout[l], L.cin_p[l], self.n_rows)
-                           for l in range(12)]
+        self.fuse_bnbwd = [bool(supported) and dtype == torch.float32 and l > 0 and self.agg_first[l]
+                           and supported(L.cout[l], L.cin_p[l], self.n_rows) for l in range(12)]
         # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
         # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
         gather_ok = getattr(ops, "spmm_bnbwd_supported", None)
@@ -187,11 +195,11 @@ class GcnEngine:
         nc = self.n_cols
 
         def buf(c):
-            return torch.empty((nc, c), dtype=torch.float32, device=dev)
+            return torch.empty((nc, c), dtype=dtype, device=dev)
 
         self.Y = [buf(L.cout[l]) for l in range(12)]                   # conv outputs (pre-BN), saved
         self.P = [buf(L.cin_p[l]) if self.agg_first[l] else None for l in range(12)]
-        self._flat = [torch.empty(nc * cmax, dtype=torch.float32, device=dev) for _ in range(6)]   # work buffers (rotation)
+        self._flat = [torch.empty(nc * cmax, dtype=dtype, device=dev) for _ in range(6)]   # work buffers (rotation)
         self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
@@ -262,7 +270,7 @@ class GcnEngine:
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
         (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
-        self._f16 = hasattr(ops, "gemm_next_scales") and ops.get_gemm_mode() == 13
+        self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
         X, pro = self.x0, None
         halo_started = False
         for l in range(12):

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ops import _p, _stream, on_device
+from .ops import _p, _stream, _timed, on_device
 
 _P = {"S1": 0, "S2": 1, "S3": 2, "S4": 3, "S5": 4, "SIG": 5}
 
@@ -427,15 +427,17 @@ class LossEngine:
         (main.py:101-102).  The BNF value is always computed; its backward is skipped when k4*gate4 == 0
         (the reference back-propagates a zero there)."""
         tb, s, loop = self.tb, self.s, self.loop
-        _vertex_fwd(tb, pos, self.real_pos, s)
-        _face_fwd(tb, pos, norm, self.real_norm, s)
-        _bnf_fwd(tb, norm, loop, s)
-        check(_lib.lib().ddmp_loss_finalize(_p(s.partials), tb.V, tb.F, self.k, float(gate4), _p(s.lossbuf), _stream()),
-              "ddmp_loss_finalize")
+        with _timed("loss_fwd", loop):
+            _vertex_fwd(tb, pos, self.real_pos, s)
+            _face_fwd(tb, pos, norm, self.real_norm, s)
+            _bnf_fwd(tb, norm, loop, s)
+            check(_lib.lib().ddmp_loss_finalize(_p(s.partials), tb.V, tb.F, self.k, float(gate4), _p(s.lossbuf), _stream()),
+                  "ddmp_loss_finalize")
         coef = s.lossbuf[6:11]
         with_bnf = (self.k_list[3] * gate4) != 0.0
-        if with_bnf:
-            _bnf_bwd(tb, loop, coef, s)
-        _face_bwd(tb, norm, self.real_norm, coef, s, with_bnf, loop, s.dnorm)
-        _vertex_bwd(tb, pos, self.real_pos, norm, coef, s, s.dpos)
+        with _timed("loss_bwd", loop if with_bnf else 0):
+            if with_bnf:
+                _bnf_bwd(tb, loop, coef, s)
+            _face_bwd(tb, norm, self.real_norm, coef, s, with_bnf, loop, s.dnorm)
+            _vertex_bwd(tb, pos, self.real_pos, norm, coef, s, s.dpos)
         return s.lossbuf, s.dpos, s.dnorm

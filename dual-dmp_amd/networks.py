@@ -57,13 +57,17 @@ class _FusedNet(nn.Module):
     _widths = None
     _kind = 0
 
-    def __init__(self, device, comm=None, reorder="morton"):
+    def __init__(self, device, comm=None, reorder="morton", dtype=torch.float32):
         """``reorder``: node numbering used INSIDE the engine ("morton" = Morton order of the node coordinates --
         smoothed vertex positions / noisy face centroids --, "bfs" = breadth-first order of the graph, None =
-        keep the caller's).  Results are returned in the caller's numbering either way."""
+        keep the caller's).  Results are returned in the caller's numbering either way.
+
+        ``dtype``: ``torch.float32`` (default) or ``torch.bfloat16`` = bf16-feature mode: node features and their
+        gradients are bfloat16 in HBM, parameters / optimizer state / outputs stay float32 (engine.GcnEngine)."""
         super().__init__()
         self.device = torch.device(device)
         self.reorder = reorder
+        self.feature_dtype = dtype
         self.layout = ArenaLayout(self._widths)
         self.arena = nn.Parameter(torch.zeros(self.layout.total, dtype=torch.float32, device=self.device))
         self.layout.init_(self.arena.data)
@@ -127,7 +131,8 @@ class _FusedNet(nn.Module):
                 graph = ops.graph_for(self._relabelled, n)
                 x0d = x0.detach().cpu()[perm].to(dev)
                 xpd = None if x_pos is None else x_pos.detach().cpu()[perm].to(dev)
-            self._engine = GcnEngine(graph, self._widths, self._kind, x0d, xpd, comm=self.comm, perm=perm)
+            self._engine = GcnEngine(graph, self._widths, self._kind, x0d, xpd, comm=self.comm, perm=perm,
+                                     dtype=self.feature_dtype)
             self._engine_key = (weakref.ref(x0), weakref.ref(edge_index), (x0._version, edge_index._version))
             pend = getattr(self, "_pending_running", None)
             if pend:

@@ -122,9 +122,26 @@ def _chk(t, dtype=torch.float32, name="tensor"):
     return t
 
 
-def _mat(t, name="matrix"):
-    """2-D float32 CUDA tensor with unit inner stride -> (tensor, leading dimension)."""
-    _chk(t, torch.float32, name)
+F32, BF16 = 0, 1            # DDMP_F32 / DDMP_BF16 of include/ddmp_hip.h (feature dtype of the dtype-tagged entry points)
+
+
+def _dt(t) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise DdmpError("feature tensors are float32 or bfloat16, got %s" % t.dtype)
+
+
+def _mat(t, name="matrix", like=None):
+    """2-D float32 / bfloat16 CUDA tensor with unit inner stride -> (tensor, leading dimension).  ``like``: a tensor
+    whose dtype it has to share (all feature operands of one call)."""
+    if isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16:
+        _chk(t, torch.bfloat16, name)
+    else:
+        _chk(t, torch.float32, name)
+    if like is not None and like.dtype != t.dtype:
+        raise DdmpError("%s is %s but the call's other feature operand is %s" % (name, t.dtype, like.dtype))
     if t.dim() != 2 or t.stride(1) != 1:
         raise DdmpError("%s must be 2-D with contiguous rows" % name)
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
@@ -235,31 +252,32 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
         raise DdmpError("x has %d rows, graph references %d nodes" % (x.shape[0], g.n_cols))
     C = x.shape[1]
     if out is None:
-        out = torch.empty((g.n_rows, C), dtype=torch.float32, device=x.device)
-    out, ldy = _mat(out, "out")
+        out = torch.empty((g.n_rows, C), dtype=x.dtype, device=x.device)
+    out, ldy = _mat(out, "out", x)
     ps, psh = (None, None) if pro is None else pro
+    es = x.element_size()
     # algorithmic bytes: every feature row read once + written once, int32 col ids, rowptr, dinv
-    alg = 2.0 * g.n_rows * C * 4 + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
+    alg = 2.0 * g.n_rows * C * es + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
     with _timed("spmm", C, alg, 2.0 * g.nnz * C):
-        st = _lib.lib().ddmp_spmm_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope,
-                                      _stream())
-    check(st, "ddmp_spmm_f32")
+        st = _lib.lib().ddmp_spmm(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
+                                  _stream())
+    check(st, "ddmp_spmm")
     return out
 
 
 def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
     """out = spmm(g, x) (a gradient dZ) and sums2 = bn_bwd_reduce(out, yp, bn4) from the same kernel."""
     x, ldx = _mat(x, "x")
-    out, ldy = _mat(out, "out")
-    yp, ldyp = _mat(yp, "yp")
+    out, ldy = _mat(out, "out", x)
+    yp, ldyp = _mat(yp, "yp", x)
     C = x.shape[1]
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_spmm_bnred_workspace_bytes(g.n_rows, C), x.device)
-    alg = 3.0 * g.n_rows * C * 4 + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
+    ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), x.device)
+    alg = 3.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
     with _timed("spmm", C, alg, 2.0 * g.nnz * C):
-        st = L.ddmp_spmm_bnred_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
-                                   _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_spmm_bnred_f32")
+        st = L.ddmp_spmm_bnred(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
+                               _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_spmm_bnred")
     return out
 
 
@@ -271,41 +289,47 @@ def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
     """out[:n_rows] = A_hat @ dY with dY = BatchNorm+LeakyReLU backward of (dz, yb) rebuilt on the gather (what
     bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
     dz, lddz = _mat(dz, "dz")
-    yb, ldyb = _mat(yb, "yb")
-    out, ldo = _mat(out, "out")
+    yb, ldyb = _mat(yb, "yb", dz)
+    out, ldo = _mat(out, "out", dz)
     C = dz.shape[1]
     assert dz.shape[0] >= g.n_cols and yb.shape[0] >= g.n_cols and out.shape[0] >= g.n_rows and yb.shape[1] == C
-    with _timed("spmm", C, 4.0 * (2 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows, 2.0 * g.nnz * C):
-        st = _lib.lib().ddmp_spmm_bnbwd_f32(g.handle, _p(dz), lddz, _p(yb), ldyb, _p(out), ldo, C, _p(bn4[0]), _p(bn4[1]),
-                                            _p(c10[0]), _p(c10[1]), slope, _stream())
-    check(st, "ddmp_spmm_bnbwd_f32")
+    es = dz.element_size()
+    with _timed("spmm", C, es * (2.0 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows, 2.0 * g.nnz * C):
+        st = _lib.lib().ddmp_spmm_bnbwd(g.handle, _p(dz), lddz, _p(yb), ldyb, _p(out), ldo, C, _dt(dz), _p(bn4[0]),
+                                        _p(bn4[1]), _p(c10[0]), _p(c10[1]), slope, _stream())
+    check(st, "ddmp_spmm_bnbwd")
     return out
 
 
 def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
     a, lda = _mat(a, "a")
-    w, ldw = _mat(w, "w")
+    w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
     n = a.shape[0] if n_rows is None else n_rows
     K, M = a.shape[1], w.shape[0]
     if w.shape[1] != K:
         raise DdmpError("gemm_nt: inner dimensions differ (%d vs %d)" % (K, w.shape[1]))
     if out is None:
-        out = torch.empty((n, M), dtype=torch.float32, device=a.device)
-    out, ldy = _mat(out, "out")
+        out = torch.empty((n, M), dtype=a.dtype, device=a.device)
+    out, ldy = _mat(out, "out", a)
     ps, psh = (None, None) if pro is None else pro
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
-    with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nt_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh),
-                                slope, _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_gemm_nt_f32")
+    ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    es = a.element_size()
+    with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_nt(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
+                            slope, _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_gemm_nt")
     return out
 
 
 def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     """gemm_nt that also fills ``sums`` (float64 [2M]) with the column sums of out and out^2 (= bn_stats(out)):
     produced in the row-panel kernel's epilogue where that kernel runs, by a separate pass otherwise."""
+    if a.dtype == torch.bfloat16:                        # bf16 features: the GEMM, then the streaming statistics pass
+        out = gemm_nt(a, w, out=out, bias=bias, pro=pro, slope=slope, n_rows=n_rows)
+        bn_stats(out, sums=sums, n_rows=n_rows)
+        return out
     a, lda = _mat(a, "a")
     w, ldw = _mat(w, "w")
     n = a.shape[0] if n_rows is None else n_rows
@@ -330,45 +354,59 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
 def gemm_nn(a, w, out=None, n_rows=None):
     """out[n,K] = a[n,M] @ w[M,K]."""
     a, lda = _mat(a, "a")
-    w, ldw = _mat(w, "w")
+    w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
     n = a.shape[0] if n_rows is None else n_rows
     M, K = w.shape
     if a.shape[1] != M:
         raise DdmpError("gemm_nn: inner dimensions differ")
     if out is None:
-        out = torch.empty((n, K), dtype=torch.float32, device=a.device)
-    out, ldy = _mat(out, "out")
+        out = torch.empty((n, K), dtype=a.dtype, device=a.device)
+    out, ldy = _mat(out, "out", a)
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
-    with _timed("gemm_nn", (M, K), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nn_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_gemm_nn_f32")
+    ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    es = a.element_size()
+    with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_nn(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_gemm_nn")
     return out
 
 
 def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
     """out[M,K] = g[n,M]^T @ f(z[n,K])  (weight gradient)."""
     g, ldg = _mat(g, "g")
-    z, ldz = _mat(z, "z")
+    z, ldz = _mat(z, "z", g)
     n = g.shape[0] if n_rows is None else n_rows
     M, K = g.shape[1], z.shape[1]
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=g.device)
-    out, ldo = _mat(out, "out")
+    out, ldo = _mat(_chk(out, torch.float32, "out"), "out")
     L = _lib.lib()
-    need = L.ddmp_gemm_tn_workspace_bytes(n, M, K)
+    need = L.ddmp_gemm_tn_ws_bytes(n, M, K, _dt(g))
     ws = Workspace.get(need, g.device)
     ps, psh = (None, None) if pro is None else pro
-    with _timed("gemm_tn", (M, K), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_tn_f32(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _p(ps), _p(psh), slope, _p(ws),
-                                ws.numel(), _stream())
-    check(st, "ddmp_gemm_tn_f32")
+    es = g.element_size()
+    with _timed("gemm_tn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_tn(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _dt(g), _p(ps), _p(psh), slope, _p(ws),
+                            ws.numel(), _stream())
+    check(st, "ddmp_gemm_tn")
     return out
 
 
-def gemm_bnbwd_supported(cout, cin, n_rows):
-    """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout over n_rows rows in the current GEMM mode?"""
+def gemm_bnbwd_supported(cout, cin, n_rows, dtype=torch.float32):
+    """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout over n_rows rows in the current GEMM mode?
+    (float32 features only: the bf16-feature GEMMs take dY as written by bn_bwd_apply.)"""
+    if dtype != torch.float32:
+        return False
     return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin), int(n_rows)))
+
+
+def to_bf16(src, dst=None):
+    """float32 -> bfloat16 (round to nearest even) on the library's kernel."""
+    src = _chk(src.contiguous(), torch.float32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(_lib.lib().ddmp_f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()), "ddmp_f32_to_bf16")
+    return dst
 
 
 def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
@@ -426,9 +464,9 @@ def bn_stats(y, sums=None, n_rows=None):
     if sums is None:
         sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
-    with _timed("bn_stats", C, 4.0 * n * C):
-        st = _lib.lib().ddmp_bn_stats_f32(_p(y), ldy, n, C, _p(sums), _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_bn_stats_f32")
+    with _timed("bn_stats", C, float(y.element_size()) * n * C):
+        st = _lib.lib().ddmp_bn_stats(_p(y), ldy, n, C, _dt(y), _p(sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_bn_stats")
     return sums
 
 
@@ -446,25 +484,25 @@ def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):
     y, ldy = _mat(y, "y")
     if out is None:
         out = torch.empty_like(y)
-    out, ldz = _mat(out, "out")
-    st = _lib.lib().ddmp_bn_lrelu_apply_f32(_p(y), ldy, _p(out), ldz, y.shape[0], y.shape[1], _p(scale), _p(shift),
-                                            slope, _stream())
-    check(st, "ddmp_bn_lrelu_apply_f32")
+    out, ldz = _mat(out, "out", y)
+    fn = _lib.lib().ddmp_bn_lrelu_apply_bf16 if y.dtype == torch.bfloat16 else _lib.lib().ddmp_bn_lrelu_apply_f32
+    st = fn(_p(y), ldy, _p(out), ldz, y.shape[0], y.shape[1], _p(scale), _p(shift), slope, _stream())
+    check(st, "ddmp_bn_lrelu_apply")
     return out
 
 
 def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None):
     dz, lddz = _mat(dz, "dz")
-    y, ldy = _mat(y, "y")
+    y, ldy = _mat(y, "y", dz)
     n = y.shape[0] if n_rows is None else n_rows
     C = y.shape[1]
     if sums2 is None:
         sums2 = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
-    with _timed("bn_bwd_reduce", C, 8.0 * n * C):
-        st = _lib.lib().ddmp_bn_bwd_reduce_f32(_p(dz), lddz, _p(y), ldy, n, C, _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
-                                               _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_bn_bwd_reduce_f32")
+    with _timed("bn_bwd_reduce", C, 2.0 * y.element_size() * n * C):
+        st = _lib.lib().ddmp_bn_bwd_reduce(_p(dz), lddz, _p(y), ldy, n, C, _dt(y), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
+                                           _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_bn_bwd_reduce")
     return sums2
 
 
@@ -478,16 +516,16 @@ def bn_bwd_prepare(sums2, n_total, bn4, dgamma, dbeta, c10):
 
 def bn_bwd_apply(dz, y, bn4, c10, dy, dbias_sums, slope=SLOPE, n_rows=None):
     dz, lddz = _mat(dz, "dz")
-    y, ldy = _mat(y, "y")
-    dy, lddy = _mat(dy, "dy")
+    y, ldy = _mat(y, "y", dz)
+    dy, lddy = _mat(dy, "dy", dz)
     n = y.shape[0] if n_rows is None else n_rows
     C = y.shape[1]
     ws = _colws(n, C, y.device)
-    with _timed("bn_bwd_apply", C, 12.0 * n * C):
-        st = _lib.lib().ddmp_bn_bwd_apply_f32(_p(dz), lddz, _p(y), ldy, _p(dy), lddy, n, C, _p(bn4[0]), _p(bn4[1]),
-                                              _p(c10[0]), _p(c10[1]), slope, _p(dbias_sums), _p(ws), ws.numel(),
-                                              _stream())
-    check(st, "ddmp_bn_bwd_apply_f32")
+    with _timed("bn_bwd_apply", C, 3.0 * y.element_size() * n * C):
+        st = _lib.lib().ddmp_bn_bwd_apply(_p(dz), lddz, _p(y), ldy, _p(dy), lddy, n, C, _dt(y), _p(bn4[0]), _p(bn4[1]),
+                                          _p(c10[0]), _p(c10[1]), slope, _p(dbias_sums), _p(ws), ws.numel(),
+                                          _stream())
+    check(st, "ddmp_bn_bwd_apply")
     return dy
 
 
@@ -512,24 +550,24 @@ def f64_to_f32(src, dst):
 def head_fwd(y, bn4, W1, b1, W2, b2, kind, x_pos, out, slope=SLOPE, n_rows=None):
     y, ldy = _mat(y, "y")
     n = y.shape[0] if n_rows is None else n_rows
-    with _timed("head_fwd", kind, 4.0 * n * (32 + 3 + (3 if kind == 0 else 0))):
-        st = _lib.lib().ddmp_head_fwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2),
-                                          _p(b2), kind, _p(x_pos), _p(out), _stream())
-    check(st, "ddmp_head_fwd_f32")
+    with _timed("head_fwd", kind, n * (32.0 * y.element_size() + 12 + (12 if kind == 0 else 0))):
+        st = _lib.lib().ddmp_head_fwd(_p(y), ldy, n, _dt(y), _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2),
+                                      _p(b2), kind, _p(x_pos), _p(out), _stream())
+    check(st, "ddmp_head_fwd")
     return out
 
 
 def head_bwd(y, bn4, W1, b1, W2, b2, kind, dout, dz, dW1, db1, dW2, db2, slope=SLOPE, n_rows=None):
     y, ldy = _mat(y, "y")
-    dz, lddz = _mat(dz, "dz")
+    dz, lddz = _mat(dz, "dz", y)
     n = y.shape[0] if n_rows is None else n_rows
     L = _lib.lib()
     ws = Workspace.get(L.ddmp_head_bwd_workspace_bytes(n), y.device)
-    with _timed("head_bwd", kind, 4.0 * n * (32 + 3 + 32)):
-        st = L.ddmp_head_bwd_f32(_p(y), ldy, n, _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2), kind,
-                                 _p(dout), _p(dz), lddz, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(ws), ws.numel(),
-                                 _stream())
-    check(st, "ddmp_head_bwd_f32")
+    with _timed("head_bwd", kind, n * (64.0 * y.element_size() + 12)):
+        st = L.ddmp_head_bwd(_p(y), ldy, n, _dt(y), _p(bn4[0]), _p(bn4[1]), slope, _p(W1), _p(b1), _p(W2), _p(b2), kind,
+                             _p(dout), _p(dz), lddz, _p(dW1), _p(db1), _p(dW2), _p(db2), _p(ws), ws.numel(),
+                             _stream())
+    check(st, "ddmp_head_bwd")
 
 
 def grad_sumsq(g, out=None):
@@ -537,7 +575,8 @@ def grad_sumsq(g, out=None):
     if out is None:
         out = torch.empty(1, dtype=torch.float64, device=g.device)
     ws = Workspace.get(L.ddmp_sumsq_workspace_bytes(), g.device)
-    st = L.ddmp_grad_sumsq_f32(_p(g), g.numel(), _p(out), _p(ws), ws.numel(), _stream())
+    with _timed("optimizer", "sumsq", 4.0 * g.numel()):
+        st = L.ddmp_grad_sumsq_f32(_p(g), g.numel(), _p(out), _p(ws), ws.numel(), _stream())
     check(st, "ddmp_grad_sumsq_f32")
     return out
 
@@ -548,8 +587,9 @@ def grad_clip_(g, sumsq, max_norm):
 
 
 def adam_step_(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, clip_sumsq=None, max_norm=0.0):
-    st = _lib.lib().ddmp_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), betas[0], betas[1], eps,
-                                       int(step), _p(clip_sumsq), float(max_norm), _stream())
+    with _timed("optimizer", "adam", 28.0 * p.numel()):
+        st = _lib.lib().ddmp_adam_step_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), betas[0], betas[1], eps,
+                                           int(step), _p(clip_sumsq), float(max_norm), _stream())
     check(st, "ddmp_adam_step_f32")
 
 
@@ -559,6 +599,7 @@ def adam_prepare(counter, lr, coef, betas=(0.9, 0.999)):
 
 
 def adam_step_dev_(p, g, m, v, coef, betas=(0.9, 0.999), eps=1e-8, clip_sumsq=None, max_norm=0.0):
-    st = _lib.lib().ddmp_adam_step_dev_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), betas[0], betas[1], eps, _p(coef),
-                                           _p(clip_sumsq), float(max_norm), _stream())
+    with _timed("optimizer", "adam", 28.0 * p.numel()):
+        st = _lib.lib().ddmp_adam_step_dev_f32(_p(p), _p(g), _p(m), _p(v), p.numel(), betas[0], betas[1], eps, _p(coef),
+                                               _p(clip_sumsq), float(max_norm), _stream())
     check(st, "ddmp_adam_step_dev_f32")

@@ -34,7 +34,7 @@ extern "C" {
 #define DDMP_ENOMEM (-3)      /* host allocation failed */
 #define DDMP_EWORKSPACE (-4)  /* caller workspace too small */
 
-#define DDMP_ABI_VERSION 1
+#define DDMP_ABI_VERSION 1      /* additions only since round 1: the *_bf16 and dtype-tagged entry points */
 
 typedef struct ddmp_graph ddmp_graph;
 typedef void* ddmp_stream;    /* hipStream_t */
@@ -281,6 +281,102 @@ int ddmp_vertex_update_f32(int64_t V, int64_t F, float* pos, const float* norm, 
 size_t ddmp_mad_workspace_bytes(void);
 int ddmp_mad_f64(int64_t F, const float* n1 /*[F,3] f32*/, const double* n2 /*[F,3] f64*/, double* out /*[1]*/,
                  void* workspace, size_t workspace_bytes, ddmp_stream stream);
+
+/* ------------------------------------------------------------------ bfloat16-feature mode (SURVEY.md §8b `dtype`)
+ * BASELINE.json configs[1] ("bf16 features"): node features, saved activations and activation gradients [N, C] are
+ * bfloat16 in HBM (raw uint16_t bits here; rows 16-byte aligned: C and every leading dimension a multiple of 8);
+ * kernels unpack to float32, accumulate in float32 (BatchNorm statistics in float64) and round to nearest-even once on
+ * the store.  Parameters, parameter gradients, optimizer state, coefficients (bias, scale, shift, c1, c0 ...) and the
+ * [n,3] outputs / loss gradients stay float32.  The GEMMs run ONE v_mfma_f32_32x32x16_bf16 product per step (the float32
+ * weights are converted to bf16 planes per call: workspace), no operand splitting and no scale slots.
+ * Each *_bf16 entry point mirrors its *_f32 namesake argument for argument; the dtype-tagged forms
+ * ddmp_spmm / ddmp_gemm_nt / ... below take `void*` features and dispatch on `dtype`.
+ */
+#define DDMP_F32 0
+#define DDMP_BF16 1
+
+int ddmp_spmm_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                   const float* bias, const float* pro_scale, const float* pro_shift, float slope, ddmp_stream stream);
+size_t ddmp_spmm_bnred_bf16_workspace_bytes(int64_t n_rows, int C);
+int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                         const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes,
+                         ddmp_stream stream);
+int ddmp_spmm_bnbwd_bf16(const ddmp_graph* g, const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb,
+                         uint16_t* out, int64_t ld_out, int C, const float* a, const float* b, const float* c1,
+                         const float* c0, float slope, ddmp_stream stream);
+/* nt / nn: K resp. M (the contraction) a multiple of 32 (nt also K = 8 | 16, the first layer), outputs <= 512 columns;
+ * workspace >= ddmp_gemm_rows_bf16_workspace_bytes(K, M) holds the bf16 weight planes */
+size_t ddmp_gemm_rows_bf16_workspace_bytes(int K, int M);
+int ddmp_gemm_nt_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                      int64_t n_rows, int K, int M, const float* bias, const float* pro_scale, const float* pro_shift,
+                      float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_gemm_nn_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                      int64_t n_rows, int M, int K, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+size_t ddmp_gemm_tn_bf16_workspace_bytes(int64_t n_rows, int M, int K);
+int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t ldz, float* dW, int64_t lddw,
+                      int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift, float slope,
+                      void* workspace, size_t workspace_bytes, ddmp_stream stream);
+/* BatchNorm passes: C a power of two in [16, 1024]; workspace = ddmp_colreduce_workspace_bytes(n_rows, C) */
+int ddmp_bn_stats_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, int C, double* sums /*[2C]*/, void* workspace,
+                       size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_lrelu_apply_bf16(const uint16_t* Y, int64_t ldy, uint16_t* Z, int64_t ldz, int64_t n_rows, int C,
+                             const float* scale, const float* shift, float slope, ddmp_stream stream);
+int ddmp_bn_bwd_reduce_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, int64_t n_rows, int C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, float slope,
+                            double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_bwd_apply_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, uint16_t* dY, int64_t lddy,
+                           int64_t n_rows, int C, const float* scale, const float* shift, const float* c1,
+                           const float* c0, float slope, double* dbias_sums /*[C]*/, void* workspace,
+                           size_t workspace_bytes, ddmp_stream stream);
+int ddmp_head_fwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                       float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                       const float* x_pos /*kind 0*/, float* out, ddmp_stream stream);
+int ddmp_head_bwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
+                       float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                       const float* dout, uint16_t* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
+                       void* workspace, size_t workspace_bytes, ddmp_stream stream);
+/* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
+int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
+int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
+
+/* dtype-tagged forms (dtype = DDMP_F32 | DDMP_BF16): what a binding of the reference's GCNConv / BatchNorm1d / Linear
+ * call sites (util/networks.py:15-26,31-44,51-67) uses when the feature dtype is a run-time choice */
+int ddmp_spmm(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
+              const float* pro_scale, const float* pro_shift, float slope, ddmp_stream stream);
+size_t ddmp_spmm_bnred_ws_bytes(int64_t n_rows, int C, int dtype);
+int ddmp_spmm_bnred(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+                    const void* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
+                    const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
+                    ddmp_stream stream);
+int ddmp_spmm_bnbwd(const ddmp_graph* g, const void* dZ, int64_t lddz, const void* Yb, int64_t ldyb, void* out,
+                    int64_t ld_out, int C, int dtype, const float* a, const float* b, const float* c1, const float* c0,
+                    float slope, ddmp_stream stream);
+size_t ddmp_gemm_rows_ws_bytes(int K, int M, int dtype);
+int ddmp_gemm_nt(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n_rows, int K,
+                 int M, int dtype, const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+                 void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_gemm_nn(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n_rows, int M,
+                 int K, int dtype, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+size_t ddmp_gemm_tn_ws_bytes(int64_t n_rows, int M, int K, int dtype);
+int ddmp_gemm_tn(const void* G, int64_t ldg, const void* Z, int64_t ldz, float* dW, int64_t lddw, int64_t n_rows, int M,
+                 int K, int dtype, const float* pro_scale, const float* pro_shift, float slope, void* workspace,
+                 size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_stats(const void* Y, int64_t ldy, int64_t n_rows, int C, int dtype, double* sums, void* workspace,
+                  size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_bwd_reduce(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t n_rows, int C, int dtype,
+                       const float* scale, const float* shift, const float* mean, const float* rstd, float slope,
+                       double* sums2, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_bn_bwd_apply(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, void* dY, int64_t lddy, int64_t n_rows,
+                      int C, int dtype, const float* scale, const float* shift, const float* c1, const float* c0,
+                      float slope, double* dbias_sums, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_head_fwd(const void* Y, int64_t ldy, int64_t n_rows, int dtype, const float* scale, const float* shift,
+                  float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                  const float* x_pos, float* out, ddmp_stream stream);
+int ddmp_head_bwd(const void* Y, int64_t ldy, int64_t n_rows, int dtype, const float* scale, const float* shift,
+                  float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
+                  const float* dout, void* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
+                  void* workspace, size_t workspace_bytes, ddmp_stream stream);
 
 #ifdef __cplusplus
 }

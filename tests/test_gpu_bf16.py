@@ -1,0 +1,399 @@
+"""bf16-feature mode (BASELINE.json configs[1]): every bf16 kernel, called through the C ABI, against float64
+restatements evaluated on the SAME bf16-rounded inputs, then the two nets and the training iteration against the oracle.
+
+Tolerances.  A bf16 kernel unpacks to float32, accumulates in float32 and rounds ONCE on the store, so against a float64
+reference on identical (already rounded) inputs an output element is off by at most half a bf16 ulp (2^-9 relative)
+plus float32 accumulation noise: asserted as |got - ref| <= 2^-8 |ref| + atol with atol scaled to the accumulation.
+Float32 outputs of bf16 inputs (weight gradients, column sums, head outputs) are float32-exact: rel-L2 <= 1e-5.
+End to end (12 layers of rounded features) the error is a property of the format, not of a kernel: the measured
+figures are asserted with ~2x head-room and written next to each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+EPS = 2.0 ** -8
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def close_bf16(got, ref, atol):
+    """elementwise: one bf16 rounding of the exact result + atol of accumulation noise"""
+    got, ref = got.double().cpu(), ref.double().cpu()
+    bad = (got - ref).abs() > EPS * ref.abs() + atol
+    return int(bad.sum()), float(((got - ref).abs() - EPS * ref.abs()).max())
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def graphs(dev):
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.mesh import Mesh
+    out = {}
+    for name, (v, f) in {"ico3": synth.icosphere(3), "grid": synth.open_grid(9, 7)}.items():
+        v, f = synth.permute_vertices(v, f, 1)
+        m = Mesh(vs=v, faces=f)
+        e = torch.tensor(m.edges.T, dtype=torch.long)
+        out[name + "_v"] = (torch.cat([e, e[[1, 0]]], 1), len(v))
+        out[name + "_f"] = (torch.from_numpy(m.f_edges), len(f))
+    return out
+
+
+def dense_ahat(ei, n):
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((ei[1], ei[0]), torch.ones(ei.shape[1], dtype=torch.float64), accumulate=True)
+    A += torch.eye(n, dtype=torch.float64)
+    d = A.sum(1).pow(-0.5)
+    return d[:, None] * A * d[None, :]
+
+
+def f_ref(x, a, b, slope=0.01):
+    z = x * a + b
+    return torch.where(z > 0, z, slope * z)
+
+
+def bn_bwd_ref(dz, y, bn4, c10, slope=0.01):
+    a, b = bn4[0].double(), bn4[1].double()
+    g = dz * torch.where(y * a + b > 0, 1.0, slope)
+    return a * g + c10[0].double() * y + c10[1].double()
+
+
+def rb(x):
+    """bf16 tensor + its exact float64 value"""
+    xb = x.to(BF)
+    return xb, xb.double()
+
+
+def test_conversion_round_to_nearest_even(dev):
+    from dual_dmp_amd import ops
+    x = torch.randn(4097, device=dev) * torch.logspace(-20, 20, 4097, device=dev)
+    x[:4] = torch.tensor([1.00390625, 1.01171875, -1.00390625, 0.0], device=dev)     # ties: to even
+    assert torch.equal(ops.to_bf16(x), x.to(BF))
+
+
+@pytest.mark.parametrize("C", [8, 16, 32, 64, 128, 256, 512, 192])
+@pytest.mark.parametrize("gname", ["ico3_v", "grid_f"])
+def test_spmm_bf16_matches_dense(dev, graphs, C, gname):
+    from dual_dmp_amd import ops
+    ei, n = graphs[gname]
+    torch.manual_seed(C)
+    xb, x = rb(torch.randn(n, C))
+    bias = torch.randn(C)
+    a, b = torch.rand(C) + 0.5, torch.randn(C)
+    A = dense_ahat(ei, n)
+    g = ops.graph_for(ei.to(dev), n)
+    y = ops.spmm(g, xb.to(dev))
+    assert y.dtype == BF
+    nbad, worst = close_bf16(y, A @ x, 1e-5)
+    assert nbad == 0, worst
+    y = ops.spmm(g, xb.to(dev), bias=bias.to(dev), pro=(a.to(dev), b.to(dev)))
+    ref = A @ f_ref(x, a.double(), b.double()) + bias.double()
+    nbad, worst = close_bf16(y, ref, 1e-5)
+    assert nbad == 0, worst
+
+
+@pytest.mark.parametrize("C", [32, 256, 64])
+def test_spmm_bf16_fused_backward_forms(dev, graphs, C):
+    """bnred: SpMM + the BatchNorm-backward column reductions of its (rounded) output; bnbwd: A_hat . dY with dY rebuilt
+    on the gather from (dZ, Y)."""
+    from dual_dmp_amd import ops
+    for gname in ("ico3_f", "grid_v"):
+        ei, n = graphs[gname]
+        torch.manual_seed(C + n)
+        A = dense_ahat(ei, n)
+        g = ops.graph_for(ei.to(dev), n)
+        xb, x = rb(torch.randn(n, C))
+        ypb, yp = rb(torch.randn(n, C) * 2 + 0.3)
+        bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5])
+        out = torch.empty(n, C, dtype=BF, device=dev)
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        ops.spmm_bnred(g, xb.to(dev), out, ypb.to(dev), bn4.to(dev), sums)
+        assert torch.equal(out, ops.spmm(g, xb.to(dev)))                # the same kernel arithmetic
+        o = out.double().cpu()
+        gg = o * torch.where(yp * bn4[0].double() + bn4[1].double() > 0, 1.0, 0.01)
+        ref = torch.cat([gg.sum(0), (gg * (yp - bn4[2].double()) * bn4[3].double()).sum(0)])
+        assert relerr(sums, ref) < 2e-5, relerr(sums, ref)              # float32 partials per 64 rows
+        # gather form
+        c10 = torch.stack([torch.randn(C) * 0.1, torch.randn(C) * 0.1])
+        dzb, dz = rb(torch.randn(n, C))
+        res = torch.empty(n, C, dtype=BF, device=dev)
+        ops.spmm_bnbwd(g, dzb.to(dev), ypb.to(dev), bn4.to(dev), c10.to(dev), res)
+        ref = A @ bn_bwd_ref(dz, yp, bn4, c10)
+        nbad, worst = close_bf16(res, ref, 2e-5)
+        assert nbad == 0, worst
+
+
+GEMM_SHAPES = [(1000, 32, 64), (777, 64, 32), (3000, 512, 512), (2049, 256, 512), (2500, 512, 256), (1500, 128, 256),
+               (1300, 256, 128), (900, 128, 64), (5000, 16, 32), (5000, 8, 32), (130, 256, 256)]
+
+
+@pytest.mark.parametrize("n,K,M", GEMM_SHAPES)
+def test_gemm_nt_bf16(dev, n, K, M):
+    """Y = f(A) W^T + b: bf16 A, float32 W (rounded to bf16 by the kernel), bf16 Y."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    ab, a = rb(torch.randn(n, K))
+    w = torch.randn(M, K) / K ** 0.5
+    wq = w.to(BF).double() if K >= 32 else w.double()          # K = 8 | 16 (first layer): plain float32 weights on the VALU
+    bias = torch.randn(M)
+    y = ops.gemm_nt(ab.to(dev), w.to(dev), bias=bias.to(dev))
+    assert y.dtype == BF and y.shape == (n, M)
+    atol = 3e-6 * float((a.abs() @ wq.abs().t()).max())
+    nbad, worst = close_bf16(y, a @ wq.t() + bias.double(), atol)
+    assert nbad == 0, worst
+    if K >= 32:
+        sc, sh = torch.rand(K) + 0.5, torch.randn(K) * 0.3
+        y = ops.gemm_nt(ab.to(dev), w.to(dev), pro=(sc.to(dev), sh.to(dev)))
+        z = f_ref(a, sc.double(), sh.double()).float().to(BF).double()       # the prologue result is rounded to bf16
+        # (the kernel rounds lrelu(fma(...)) computed in float32: identical up to float32 rounding before the bf16 one,
+        #  which can move an element by one bf16 ulp -- hence the rel-L2 form)
+        assert relerr(y, z @ wq.t()) < 4e-3
+
+
+@pytest.mark.parametrize("n,M,K", [(1000, 64, 32), (3000, 512, 512), (2049, 512, 256), (2500, 256, 512), (900, 32, 64),
+                                    (1300, 128, 256), (130, 256, 256)])
+def test_gemm_nn_bf16(dev, n, M, K):
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    ab, a = rb(torch.randn(n, M))
+    w = torch.randn(M, K) / M ** 0.5
+    wq = w.to(BF).double()
+    y = ops.gemm_nn(ab.to(dev), w.to(dev))
+    assert y.dtype == BF and y.shape == (n, K)
+    atol = 3e-6 * float((a.abs() @ wq.abs()).max())
+    nbad, worst = close_bf16(y, a @ wq, atol)
+    assert nbad == 0, worst
+
+
+@pytest.mark.parametrize("n,M,K", [(1000, 64, 32), (40000, 512, 512), (20000, 256, 512), (3000, 512, 256), (777, 32, 16),
+                                    (5000, 32, 8), (9000, 128, 64), (2500, 256, 256), (33, 64, 64)])
+def test_gemm_tn_bf16(dev, n, M, K):
+    """dW = G^T f(Z): bf16 operands, float32 result; exercises the ds_read_b64_tr_b16 fragment path with asymmetric data."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    gb, g = rb(torch.randn(n, M) * torch.linspace(0.5, 2.0, M))
+    zb, z = rb(torch.randn(n, K) + torch.linspace(-1.0, 1.0, K))
+    dw = ops.gemm_tn(gb.to(dev), zb.to(dev))
+    assert dw.dtype == torch.float32 and dw.shape == (M, K)
+    assert relerr(dw, g.t() @ z) < 1e-5, relerr(dw, g.t() @ z)
+    sc, sh = torch.rand(K) + 0.5, torch.randn(K) * 0.3
+    dw = ops.gemm_tn(gb.to(dev), zb.to(dev), pro=(sc.to(dev), sh.to(dev)))
+    zz = f_ref(z, sc.double(), sh.double()).float().to(BF).double()
+    assert relerr(dw, g.t() @ zz) < 2e-3
+
+
+@pytest.mark.parametrize("C", [16, 32, 128, 512])
+def test_batchnorm_passes_bf16(dev, C):
+    from dual_dmp_amd import ops
+    n = 3001
+    torch.manual_seed(C)
+    yb, y = rb(torch.randn(n, C) * 1.7 + 0.4)
+    dzb, dz = rb(torch.randn(n, C))
+    sums = ops.bn_stats(yb.to(dev))
+    assert relerr(sums, torch.cat([y.sum(0), (y * y).sum(0)])) < 1e-12
+    bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), y.mean(0).float(), torch.rand(C) + 0.5])
+    s2 = ops.bn_bwd_reduce(dzb.to(dev), yb.to(dev), bn4.to(dev))
+    gg = dz * torch.where(y * bn4[0].double() + bn4[1].double() > 0, 1.0, 0.01)
+    ref = torch.cat([gg.sum(0), (gg * ((y.float() - bn4[2]) * bn4[3]).double()).sum(0)])
+    assert relerr(s2, ref) < 1e-6
+    c10 = torch.stack([torch.randn(C) * 0.1, torch.randn(C) * 0.1])
+    dy = torch.empty(n, C, dtype=BF, device=dev)
+    db = torch.empty(2 * C, dtype=torch.float64, device=dev)
+    ops.bn_bwd_apply(dzb.to(dev), yb.to(dev), bn4.to(dev), c10.to(dev), dy, db)
+    nbad, worst = close_bf16(dy, bn_bwd_ref(dz, y, bn4, c10), 1e-6)
+    assert nbad == 0, worst
+    assert relerr(db[:C], dy.double().sum(0)) < 1e-12                   # column sums of the values as stored
+    z = ops.bn_lrelu_apply(yb.to(dev), bn4[0].to(dev), bn4[1].to(dev))
+    nbad, worst = close_bf16(z, f_ref(y, bn4[0].double(), bn4[1].double()), 1e-6)
+    assert nbad == 0, worst
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_heads_bf16_equal_the_float32_heads_on_the_same_values(dev, kind):
+    from dual_dmp_amd import ops
+    n = 1500
+    torch.manual_seed(kind)
+    yb = (torch.randn(n, 32) * 1.5).to(BF).to(dev)
+    bn4 = torch.stack([torch.rand(32) + 0.5, torch.randn(32) * 0.2, torch.zeros(32), torch.ones(32)]).to(dev)
+    W1, b1 = (torch.randn(16, 32) * 0.2).to(dev), (torch.randn(16) * 0.1).to(dev)
+    W2, b2 = (torch.randn(3, 16) * 0.3).to(dev), (torch.randn(3) * 0.1).to(dev)
+    xp = torch.randn(n, 3, device=dev)
+    dout = torch.randn(n, 3, device=dev)
+    res = {}
+    for name, y in (("bf16", yb), ("f32", yb.float())):
+        out = torch.empty(n, 3, device=dev)
+        ops.head_fwd(y, bn4, W1, b1, W2, b2, kind, xp, out)
+        dz = torch.empty(n, 32, dtype=y.dtype, device=dev)
+        gr = [torch.empty_like(t) for t in (W1, b1, W2, b2)]
+        ops.head_bwd(y, bn4, W1, b1, W2, b2, kind, dout, dz, *gr)
+        res[name] = (out, dz, gr)
+    assert torch.equal(res["bf16"][0], res["f32"][0])
+    assert torch.equal(res["bf16"][1], res["f32"][1].to(BF))
+    for a, b in zip(res["bf16"][2], res["f32"][2]):
+        assert torch.equal(a, b)
+
+
+def _nets(dev, oracle, dtype, mesh="ico3"):
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    v, f = synth.icosphere(3) if mesh == "ico3" else synth.open_grid(24, 17)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+    torch.manual_seed(0)
+    ref_pos, ref_norm = oracle.PosNetRef(), oracle.NormalNetRef()
+    posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
+    posnet.load_state_dict(ref_pos.state_dict())
+    normnet.load_state_dict(ref_norm.state_dict())
+    return gt, noisy, smooth, data, ref_pos, ref_norm, posnet, normnet
+
+
+@pytest.mark.parametrize("mesh", ["ico3", "grid"])
+def test_nets_bf16_forward_backward_vs_oracle(dev, oracle, mesh):
+    """Whole-net forward and parameter gradients of the bf16-feature mode against the float32 oracle from identical
+    (random-init) weights.  Measured on MI355X (this test prints them; ico3 / grid): forward max|dpos| 1.1e-2 on a
+    unit-edge mesh, max|dnorm| 0.15 (rms ~2e-2: unit normals of tiny tanh arguments amplify the relative error),
+    weight-gradient rel-L2 0.14 / 0.20 -- not kernel error (every kernel is exact to one rounding, tests above, and the
+    forward pass reproduces a rounding-by-rounding emulation, test below) but what 12 layers of 8-bit significands do:
+    ~0.4 % of the LeakyReLU units sit within a bf16 ulp of zero and take the other slope.  Asserted with ~2x head-room."""
+    gt, noisy, smooth, data, ref_pos, ref_norm, posnet, normnet = _nets(dev, oracle, BF, mesh)
+    odata = oracle.OracleDataset(noisy, smooth)
+    pos, norm = posnet(data), normnet(data)
+    rp, rn = ref_pos(odata), ref_norm(odata)
+    e_p = float((pos.detach().cpu() - rp.detach()).abs().max())
+    e_n = float((norm.detach().cpu() - rn.detach()).abs().max())
+    r_p = float((pos.detach().cpu() - rp.detach()).pow(2).mean().sqrt())
+    r_n = float((norm.detach().cpu() - rn.detach()).pow(2).mean().sqrt())
+    # a fixed linear functional of the outputs as the loss: gradients of every layer
+    torch.manual_seed(1)
+    gp, gn = torch.randn_like(rp), torch.randn_like(rn)
+    (pos * gp.to(dev)).sum().backward()
+    (norm * gn.to(dev)).sum().backward()
+    (rp * gp).sum().backward()
+    (rn * gn).sum().backward()
+    errs = {}
+    for net, ref, tag in ((posnet, ref_pos, "pos"), (normnet, ref_norm, "norm")):
+        gv = net.named_views(grads=True)
+        num = den = 0.0
+        for name, p in ref.named_parameters():
+            if name.startswith("conv") and name.endswith(".bias"):
+                continue                                    # analytically zero after BatchNorm (rounding noise only)
+            num += float((gv[name].cpu().double() - p.grad.double()).pow(2).sum())
+            den += float(p.grad.double().pow(2).sum())
+        errs[tag] = (num / den) ** 0.5
+    print("bf16 nets on %s: max|dpos| %.2e (rms %.2e)  max|dnorm| %.2e (rms %.2e)  grad rel-L2 pos %.2e norm %.2e"
+          % (mesh, e_p, r_p, e_n, r_n, errs["pos"], errs["norm"]))
+    assert e_p < 2.5e-2 and e_n < 0.3 and r_p < 6e-3 and r_n < 6e-2, (e_p, e_n, r_p, r_n)
+    assert errs["pos"] < 0.4 and errs["norm"] < 0.4, errs
+
+
+def _emulate_forward(oracle_net, A, x0, kind, x_pos, dev):
+    """The bf16-feature forward pass restated rounding by rounding in float64 torch (test infrastructure): what each HIP
+    kernel stores is bf16(exact result of bf16-rounded inputs); statistics from the stored values."""
+    sd = {k: v.detach() for k, v in oracle_net.state_dict().items()}
+
+    def r(t):
+        return t.float().to(BF).double()
+
+    def f(x, a, b):
+        z = (x.float() * a + b)                                   # kernels: fmaf in float32
+        return torch.where(z > 0, z, 0.01 * z).double()
+
+    X, pro = r(x0.double()), None
+    widths = [x0.shape[1]] + [sd["conv%d.bias" % i].numel() for i in range(1, 13)]
+    n = x0.shape[0]
+    for l in range(12):
+        W, b = sd["conv%d.lin.weight" % (l + 1)].double(), sd["conv%d.bias" % (l + 1)].double()
+        cin = (widths[l] + 3) // 4 * 4
+        Z = X if pro is None else f(X, *pro)
+        if cin <= widths[l + 1]:
+            P = r(A @ Z)
+            Wq = W if l == 0 else r(W)
+            Y = r(P @ Wq.t() + b)
+        else:
+            H = r(r(Z) @ r(W).t())
+            Y = r(A @ H + b)
+        mu = Y.sum(0) / n
+        var = ((Y * Y).sum(0) / n - mu * mu).clamp_min(0)
+        rs = (1.0 / (var + 1e-5).sqrt()).float()
+        a = sd["bn%d.weight" % (l + 1)] * rs
+        sh = torch.addcmul(sd["bn%d.bias" % (l + 1)], -mu.float(), a)
+        X, pro = Y, (a, sh)
+    z = f(X, *pro).float()
+    t = torch.nn.functional.leaky_relu(z @ sd["linear1.weight"].t() + sd["linear1.bias"], 0.01)
+    u = t @ sd["linear2.weight"].t() + sd["linear2.bias"]
+    if kind == 0:
+        return x_pos.float() + u
+    v = torch.tanh(u)
+    return v / (v.norm(dim=1, keepdim=True) + 1e-12)
+
+
+def test_bf16_forward_reproduces_the_rounding_emulation(dev, oracle):
+    """Wiring of the bf16 engine: against an emulation that rounds where the kernels round, the forward pass agrees to a
+    small fraction of the format's own error (the residue: float32 vs float64 accumulation moving an element across a
+    rounding boundary now and then).  Measured: max|dpos| ~1e-4, max|dnorm| ~2e-3, i.e. 50-100x below the distance to
+    the float32 oracle."""
+    gt, noisy, smooth, data, ref_pos, ref_norm, posnet, normnet = _nets(dev, oracle, BF, "ico3")
+    V, F = len(noisy.vs), len(noisy.faces)
+    Av, Af = dense_ahat(data.edge_index, V), dense_ahat(data.face_index, F)
+    pos, norm = posnet(data).detach().cpu(), normnet(data).detach().cpu()
+    epos = _emulate_forward(ref_pos, Av, data.z1.detach(), 0, data.x_pos.detach(), dev)
+    enorm = _emulate_forward(ref_norm, Af, data.z2.detach(), 1, None, dev)
+    e_p, e_n = float((pos - epos).abs().max()), float((norm - enorm).abs().max())
+    r_p, r_n = float((pos - epos).pow(2).mean().sqrt()), float((norm - enorm).pow(2).mean().sqrt())
+    print("bf16 forward vs rounding emulation: max|dpos| %.2e (rms %.2e)  max|dnorm| %.2e (rms %.2e)" % (e_p, r_p, e_n, r_n))
+    assert r_p < 5e-4 and r_n < 5e-3, (e_p, e_n, r_p, r_n)
+
+
+def test_training_bf16_tracks_float32(dev, oracle):
+    """30 free-running iterations from identical weights: the bf16-feature run against the float32 HIP run.  Measured on
+    MI355X: loss within a few % of the float32 run, MAD within 0.3 degrees (the spread of float32 runs across seeds is of
+    the same size); asserted: loss within 10 %, MAD within 1 degree, both improving on the noisy input."""
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.loss import mad
+    from dual_dmp_amd.mesh import Mesh
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    v, f = synth.icosphere(4)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+    out = {}
+    for dtype in (torch.float32, BF):
+        torch.manual_seed(0)
+        posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
+        tr = FusedTrainer(posnet, normnet, data, noisy)
+        losses = [float(tr.step().item()) for _ in range(30)]
+        o = Mesh.__new__(Mesh)
+        o.vs, o.faces = tr.pos.cpu().numpy().astype(np.float64), noisy.faces
+        Mesh.compute_face_normals(o)
+        out[dtype] = (losses, float(mad(o.fn, gt.fn)))
+    m0 = float(mad(noisy.fn, gt.fn))
+    (l32, m32), (l16, m16) = out[torch.float32], out[BF]
+    print("30 iterations: loss f32 %.4f bf16 %.4f | MAD noisy %.3f f32 %.3f bf16 %.3f" % (l32[-1], l16[-1], m0, m32, m16))
+    assert abs(l16[0] - l32[0]) <= 2e-3 * abs(l32[0])        # first iteration: same weights, forward error only
+    assert l16[-1] < l16[0] and abs(l16[-1] - l32[-1]) <= 0.1 * abs(l32[-1])
+    assert m16 < m0 and abs(m16 - m32) <= 1.0
+
+
+def test_c_abi_dtype_argument_is_checked(dev):
+    import ctypes
+    from dual_dmp_amd import _lib
+    L = _lib.lib()
+    y = torch.zeros(64, 32, device=dev)
+    s = torch.zeros(64, dtype=torch.float64, device=dev)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    st = L.ddmp_bn_stats(ctypes.c_void_p(y.data_ptr()), 32, 64, 32, 7, ctypes.c_void_p(s.data_ptr()),
+                         ctypes.c_void_p(ws.data_ptr()), ws.numel(), None)
+    assert st == -1
