@@ -149,6 +149,56 @@ def test_training_iteration_invariances_at_1m(big):
     assert res[0][2] + res[1][2] == len(noisy.vs)
 
 
+def test_eight_rank_partition_at_1m_cad_recipe_gate_open(big):
+    """BASELINE.json configs[3]'s shape on the one GPU of the test box: 8 logical ranks (threads, ThreadComm) over the
+    1,000,000-face mesh, Morton face partition + 1-hop halos, with the CAD recipe (k = (3, 0, 3, 4, 2), bnfloop 5) and
+    the BNF gate open (epoch 101).  Every rank must reproduce the unpartitioned iteration: loss to 1e-6 relative,
+    positions to 5e-5 (float32 summation order), and the shards must tile the mesh."""
+    from dual_dmp_amd import dist as D
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    dev = torch.device("cuda:0")
+    gt, noisy, smooth, data = big
+    K = (3.0, 0.0, 3.0, 4.0, 2.0)
+    torch.manual_seed(0)
+    tr = FusedTrainer(PosNet(dev), NormalNet(dev), data, noisy, bnfloop=5, k=K)
+    tr.epoch = 100
+    base_loss = tr.step().item()
+    base_pos = tr.pos.clone()
+    assert float(tr.lossbuf[3].item()) > 0.0                                         # the BNF term is live
+    del tr
+    torch.cuda.empty_cache()
+
+    P = 8
+    nets = []
+    for _ in range(P):
+        torch.manual_seed(0)
+        nets.append((PosNet(dev), NormalNet(dev)))
+    comms = D.ThreadComm.make(P)
+    res, errs = {}, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            t = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, backend=comms[r], nets=nets[r], bnfloop=5, k=K)
+            t.epoch = 100
+            res[r] = (t.step().item(), t.pos.clone(), t.peng.n_rows, t.peng.n_cols, t.neng.n_rows)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            comms[r].s.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for r in range(P):
+        loss, pos, n_rows, n_cols, f_rows = res[r]
+        assert n_rows < n_cols
+        assert abs(loss - base_loss) <= 1e-6 * abs(base_loss), (r, loss, base_loss)
+        assert float((pos - base_pos).abs().max()) < 5e-5, r
+    assert sum(res[r][2] for r in range(P)) == len(noisy.vs) and sum(res[r][4] for r in range(P)) == len(noisy.faces)
+
+
 def test_fused_engine_matches_unfused_kernels_at_140k():
     """Above 64k rows the engine takes its fused routes (BatchNorm statistics from the GEMM epilogue, BatchNorm backward
     rebuilt on the dgrad/wgrad operand loads, backward reductions from the SpMM epilogue, row-panel GEMMs).  GEMM mode 0

@@ -110,7 +110,9 @@ def test_loss_ltype_conventions(dev, golden_dir):
 def _case(dev, which="ico3"):
     from dual_dmp_amd import synth
     from dual_dmp_amd.datamaker import dataset_from_meshes
-    v, f = synth.icosphere(3) if which == "ico3" else synth.open_grid(12, 9)
+    v, f = {"ico3": lambda: synth.icosphere(3), "grid": lambda: synth.open_grid(12, 9),
+            "cad33": lambda: synth.cube_cad(33),         # 13,068 faces: the fandisk stand-in (README.md:57 of the reference)
+            "grid24": lambda: synth.open_grid(24, 17)}[which]()
     v, f = synth.permute_vertices(v, f, 3)
     gt, noisy, smooth = synth.make_triplet(v, f)
     return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
@@ -234,8 +236,13 @@ def _snapshot(net, opt):
     return sd, m, v
 
 
-@pytest.mark.parametrize("bnfloop,ep0", [(1, 0), (5, 100)])
-def test_training_step_teacher_forced(dev, oracle, bnfloop, ep0):
+DEFAULT_K = (3.0, 4.0, 4.0, 4.0, 1.0)                    # main.py:22-26
+CAD_K = (3.0, 0.0, 3.0, 4.0, 2.0)                        # README.md:57 (CAD recipe) == main4real.py:19-23 defaults
+
+
+@pytest.mark.parametrize("bnfloop,ep0,which,k", [(1, 0, "ico3", DEFAULT_K), (5, 100, "ico3", DEFAULT_K),
+                                                 (5, 100, "cad33", CAD_K)])
+def test_training_step_teacher_forced(dev, oracle, bnfloop, ep0, which, k):
     """Strict per-iteration parity of main.py:88-110.  The oracle runs 6 iterations; before iterations
     1, 2, 4 and 6 its complete state (weights, BatchNorm buffers, Adam moments, step count) is injected into
     the HIP trainer, which then takes ONE iteration.  Compared: loss (rel 1e-5), the five loss terms, pos / norm
@@ -245,21 +252,35 @@ def test_training_step_teacher_forced(dev, oracle, bnfloop, ep0):
     LeakyReLU knife edges: one element with BN(y) within an ulp of 0 takes slope 1 or 0.01 depending on
     last-bit rounding, which moves one channel's gradient by ~1e-3..1e-2 in ANY float32 arithmetic (measured:
     the float32 oracle and the HIP path agree to 2e-7 on such a channel while both sit 7e-2 from float64).
-    Conv biases are excluded: their gradient is analytically zero after BatchNorm."""
+    Conv biases are excluded: their gradient is analytically zero after BatchNorm.
+
+    Cases: the defaults of main.py with the BNF gate closed and open, and BASELINE.json configs[0]'s shape -- the README
+    CAD recipe (--k1 3 --k2 0 --k3 3 --k4 4 --k5 2 --bnfloop 5) on the fandisk-size cube (13,068 faces), gate open."""
+    _teacher_forced(dev, oracle, which, k, bnfloop, ep0, 6, (1, 2, 4, 6))
+
+
+def test_main4real_defaults_teacher_forced_over_50_iterations(dev, oracle):
+    """BASELINE.json configs[4] (main4real.py --iter 50: k = (3, 0, 3, 4, 2), bnfloop 5, no ground truth, the BNF gate
+    stays closed below epoch 100) on an open-boundary mesh: the oracle runs all 50 iterations, the HIP trainer is given
+    its state before iterations 1, 10, 25 and 50 and must reproduce that iteration (same bounds as above)."""
+    _teacher_forced(dev, oracle, "grid24", CAD_K, 5, 0, 50, (1, 10, 25, 50))
+
+
+def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at):
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
-    gt, noisy, smooth, data = _case(dev, "ico3")
+    gt, noisy, smooth, data = _case(dev, which)
     torch.manual_seed(11)
     sd_pos, sd_norm = oracle.PosNetRef().state_dict(), oracle.NormalNetRef().state_dict()
     rp, rn = _oracle_nets(oracle, sd_pos, sd_norm)
     odata, omesh = _oracle_inputs(oracle, noisy, smooth, torch.float32)
-    args = oracle.StepArgs(bnfloop=bnfloop)
+    args = oracle.StepArgs(bnfloop=bnfloop, k1=k[0], k2=k[1], k3=k[2], k4=k[3], k5=k[4])
     op = torch.optim.Adam(rp.parameters(), lr=args.pos_lr)
     on = torch.optim.Adam(rn.parameters(), lr=args.norm_lr)
     posnet, normnet = PosNet(dev), NormalNet(dev)
-    tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=bnfloop)
-    for it in range(1, 7):
-        if it in (1, 2, 4, 6):
+    tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=bnfloop, k=k)
+    for it in range(1, iters + 1):
+        if it in check_at:
             for which, (net, ref, opt) in enumerate(((posnet, rp, op), (normnet, rn, on))):
                 sd, m, v = _snapshot(ref, opt)
                 net.load_state_dict(sd)
@@ -269,7 +290,7 @@ def test_training_step_teacher_forced(dev, oracle, bnfloop, ep0):
             g32 = _oracle_grads(oracle, rp, rn, noisy, smooth, args, ep0 + it, torch.float32)
             g64 = _oracle_grads(oracle, rp, rn, noisy, smooth, args, ep0 + it, torch.float64)
         ref_loss, ref_pos, ref_norm, parts = oracle.train_step(rp, rn, op, on, odata, omesh, args, ep0 + it)
-        if it not in (1, 2, 4, 6):
+        if it not in check_at:
             continue
         loss = tr.step().item()
         assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss), (it, loss, ref_loss)
