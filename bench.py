@@ -324,9 +324,10 @@ def main():
         loss = tr.step().item()          # the reference's per-step sync (main.py:113)
     sync()
     elapsed = time.perf_counter() - t0
-    scale_overflow = None                # f16x3 GEMM mode: did an operand outgrow its scale (values clamped)?
+    scale_overflow = None                # f16x3 GEMM mode: operands that outgrew their scale are redone on the device
+    healed = 0                           # (gemm_f16s.inc); only non-finite operands are an error
     try:
-        tr.check_scales()
+        healed = tr.check_scales()
     except OverflowError as e:
         scale_overflow = str(e)
     if multi:
@@ -454,7 +455,7 @@ def main():
                        "two_streams": bool(args.overlap) and not multi},
             "loss": round(float(loss), 6),
             "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
-            "gemm_scale_overflow": scale_overflow,
+            "gemm_scale_overflow": scale_overflow, "gemm_scale_healed": healed,
         }
         line.update(out)
         if args.kernel_table:

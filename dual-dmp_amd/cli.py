@@ -84,10 +84,9 @@ def run(argv=None, real: bool = False):
         if epoch % 10 == 0 or epoch == args.iter:
             print("Epoch {}: loss={:.6f}".format(epoch, loss) + ("" if mad_value is None else " mad={:.3f}".format(mad_value)))
         if epoch % 10 == 0:
-            try:
-                tr.check_scales()
-            except OverflowError as e:                           # transient: the scales follow the data one iteration later
-                print("[WARN] " + str(e))
+            healed = tr.check_scales()                           # OverflowError (non-finite operands) is fatal: let it out
+            if healed:
+                print("[INFO] %d f16x3 GEMM operand(s) outgrew their scale and were recomputed with the measured one" % healed)
             if ev is not None:
                 mad_value = ev.mad(tr.pos)
             if real or epoch % 100 == 0:

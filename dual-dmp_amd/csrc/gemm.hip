@@ -506,13 +506,17 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
         const int target = prime ? kF16TargetExact : kF16TargetStale;
         const void* Bh = planes;
-#define DDMP_PANEL_H(WR_, WC_, AR_)                                                                               \
+#define DDMP_PANEL_H(WR_, WC_, AR_, HEAL_)                                                                        \
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, AR_, PM, 4>), grid, block, 0, st, A, lda, A2, lda2, Bh, Y, ldy,   \
-                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, slot, (const float*)wscale, target)
-        if (WC == 4) {
-            DDMP_PANEL_H(2, 4, 13);
-        } else {
-            DDMP_PANEL_H(4, 2, 13);
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, slot, (const float*)wscale, \
+                       target, HEAL_)
+        // stale scale in use: a second launch redoes the product if (and only if) an operand outgrew it (gemm_f16s.inc)
+        for (int heal = 0; heal <= (prime ? 0 : 1); ++heal) {
+            if (WC == 4) {
+                DDMP_PANEL_H(2, 4, 13, heal);
+            } else {
+                DDMP_PANEL_H(4, 2, 13, heal);
+            }
         }
 #undef DDMP_PANEL_H
         if (stats && sums) {
@@ -529,7 +533,7 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
 #define DDMP_PANEL(WR_, WC_, NT_, NJ_)                                                                            \
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM, NJ_>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy, \
                        n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, (float*)nullptr,            \
-                       (const float*)nullptr, 0)
+                       (const float*)nullptr, 0, 0)
     if (WC == 4) {
         if (mode == 6) DDMP_PANEL(2, 4, 3, 4); else DDMP_PANEL(2, 4, 2, 4);
     } else if (WC == 2) {
@@ -769,12 +773,12 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
         dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
         float* gslot = nullptr;
         float* zslot = nullptr;
-        int target = 0;
+        int target = 0, heal_ = 0;
 #define DDMP_LAUNCH_TNP(KERNEL_)                                                                              \
     hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, G, ldg, (const float*)nullptr, (int64_t)0, Z, ldz, part, \
                        (int64_t)K, sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k,       \
                        p.n_splits, pro_scale, pro_shift, (const float*)nullptr, (const float*)nullptr,           \
-                       (const float*)nullptr, (const float*)nullptr, slope, gslot, zslot, target)
+                       (const float*)nullptr, (const float*)nullptr, slope, gslot, zslot, target, heal_)
         const int mode_ = gemm_mode();
         if (mode_ == 6 && gemm_f16()) {
             float* tail = (float*)((char*)workspace + need - 64);
@@ -788,11 +792,14 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
                 if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
                 else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
             }
-            if (pro_scale) {
-                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, false>));
-            } else {
-                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, false>));
+            for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {      // second launch: redo on overflow (gemm_f16s.inc)
+                if (pro_scale) {
+                    DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, false>));
+                } else {
+                    DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, false>));
+                }
             }
+            heal_ = 0;
         } else if (pro_scale) {
             if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, false>));
         } else {
@@ -877,11 +884,11 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
     float* gslot = nullptr;
     float* zslot = nullptr;
-    int target = 0;
+    int target = 0, heal_ = 0;
 #define DDMP_LAUNCH_TNP(KERNEL_)                                                                                 \
     hipLaunchKernelGGL((KERNEL_), pgrid, pblock, 0, st, dZ, lddz, Yb, ldyb, Z, ldz, part, (int64_t)K, sstride,     \
                        (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale,       \
-                       pro_shift, a, b, c1, c0, slope, gslot, zslot, target)
+                       pro_shift, a, b, c1, c0, slope, gslot, zslot, target, heal_)
     const int mode_ = gemm_mode();
     if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0) {
         float* tail = (float*)((char*)workspace + need - 64);
@@ -895,11 +902,14 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
             if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
             else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
         }
-        if (pro_scale) {
-            DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, true>));
-        } else {
-            DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, true>));
+        for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {          // second launch: redo on overflow (gemm_f16s.inc)
+            if (pro_scale) {
+                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, true>));
+            } else {
+                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, true>));
+            }
         }
+        heal_ = 0;
     } else if (pro_scale) {
         if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, true>));
     } else {

@@ -357,9 +357,8 @@ class DistributedTrainer:
     def gather_pos(self):
         return self.full[: self.sd.V]
 
-    def check_scales(self):
-        self.peng.check_scales()
-        self.neng.check_scales()
+    def check_scales(self) -> int:
+        return self.peng.check_scales() + self.neng.check_scales()
 
     @torch.no_grad()
     def step(self):

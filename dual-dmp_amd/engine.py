@@ -233,15 +233,23 @@ class GcnEngine:
         if self._f16:
             ops.gemm_next_scales(self._slot[l][a], None if b is None else self._slot[l][b], self._prime)
 
-    def check_scales(self):
-        """f16 split modes: raise if an operand outgrew its scale (values were clamped) since the last check.  Syncs."""
-        flags = self.scale_slots[:, :, 2].view(torch.int32)
-        if bool(flags.any().item()):
-            where = [(int(l), int(o)) for l, o in flags.nonzero().tolist()]
-            flags.zero_()
-            self._prime = True                                   # measure again on the next (eager) iteration
-            raise OverflowError("GEMM operand exceeded its f16 scale (layer, operand): %s -- values were clamped in the "
-                                "last iterations; re-run them (DDMP_GEMM_MODE=6 avoids scaled operands)" % where)
+    def check_scales(self) -> int:
+        """f16 split modes.  An operand that outgrows its (one iteration old) scale is never computed with clamped:
+        the GEMM call re-launches itself on the device and redoes the product with the measured maximum
+        (csrc/gemm_f16s.inc, "self-healing"); the per-iteration roll counts those events per slot.  Returns the number
+        of healed events since the last call (and resets the counters); raises OverflowError only when an operand was
+        not finite (NaN / inf activations or gradients: nothing to heal).  Syncs."""
+        cnt = self.scale_slots[:, :, 3]
+        c = cnt.cpu()
+        if bool((c < 0).any()):
+            where = [(int(l), int(o)) for l, o in (c < 0).nonzero().tolist()]
+            cnt.zero_()
+            raise OverflowError("non-finite GEMM operand (layer, operand): %s -- NaN or inf in the activations / "
+                                "gradients of the last iterations" % where)
+        healed = int(c.sum().item())
+        if healed:
+            cnt.zero_()
+        return healed
 
     # ------------------------------------------------------------------ forward
     def _side_stream(self):

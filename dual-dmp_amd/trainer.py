@@ -118,10 +118,11 @@ class FusedTrainer:
         return lossbuf, pos, norm
 
     @torch.no_grad()
-    def check_scales(self):
-        """f16 split GEMM modes: raise OverflowError if an operand outgrew its scale since the last check (syncs)."""
-        self.peng.check_scales()
-        self.neng.check_scales()
+    def check_scales(self) -> int:
+        """f16 split GEMM modes: number of GEMM operands that outgrew their scale since the last call -- each was redone
+        on the device with the measured scale before anything consumed it (GcnEngine.check_scales); raises
+        OverflowError for non-finite operands.  Syncs."""
+        return self.peng.check_scales() + self.neng.check_scales()
 
     def step(self):
         with ops.on_device(self.device):

@@ -102,12 +102,15 @@ size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
  *        are accumulated in f32 (the "3xTF32" scheme; csrc/gemm_f16s.inc) -- f32-class accuracy, half the MFMA work;
  *   3  = bf16x3 (three products, ~2^-16 relative);   0 = f32-input MFMA (v_mfma_f32_32x32x2_f32).
  * Mode 13's power of two comes from the operand's absolute maximum, kept in a "scale slot" (device float[4]: {maximum
- * in use, maximum seen by the last kernels, overflow flag, -}).  By default the library measures it in a pre-pass over
+ * in use, maximum seen by the last kernels, overflow flag, healed events}).  By default the library measures it in a pre-pass over
  * the operand.  A training loop avoids that pass: ddmp_gemm_next_scales names persistent slots for the NEXT ddmp_gemm_*
  * call of this host thread (slot_a: the row operand A / dZ / G; slot_b: Z of the tn forms; prime != 0: measure now
  * anyway, e.g. first iteration), the GEMM kernels record the maximum they see, and ddmp_gemm_scales_roll, once per
- * iteration, makes it the next iteration's scale (6 bits of head-room; anything that still overflows is clamped to the
- * f16 range and raises the slot's flag). */
+ * iteration, makes it the next iteration's scale (6 bits of head-room).  An operand that still outgrows its scale raises
+ * the slot's flag ([2]) and is HEALED inside the same ddmp_gemm_* call: the kernel is launched a second time, returns at
+ * once while the flag is clear and otherwise redoes the product with the maximum the first launch has just recorded
+ * ([1]), overwriting the clamped result before the caller's next kernel sees it.  ddmp_gemm_scales_roll counts healed
+ * events per slot in [3] (-1: the operand was not finite) and clears the flag. */
 int ddmp_set_gemm_mode(int mode);
 int ddmp_get_gemm_mode(void);
 int ddmp_gemm_next_scales(float* slot_a, float* slot_b, int prime);

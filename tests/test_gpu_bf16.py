@@ -336,7 +336,7 @@ def test_bf16_engine_layer_by_layer_against_rounding_emulation(dev, oracle):
                 H = r(r(Z) @ r(W).t())
                 Y = r(A @ H + b)
             got = eng.Y[l].cpu().double()
-            ulp = 2.0 ** (torch.floor(torch.log2(Y.abs().clamp_min(1e-30))) - 7)       # bf16: 8 significant bits
+            ulp = 2.0 ** (torch.floor(torch.log2(torch.maximum(Y.abs(), got.abs()).clamp_min(1e-30))) - 7)    # bf16: 8 significant bits
             d = (got - Y).abs()
             assert bool((d <= 1.001 * ulp).all()), (l, float((d / ulp).max()))
             frac = float((d > 0).double().mean())

@@ -270,7 +270,9 @@ def test_f16x3_operand_scaling(dev, f16x3, scale):
 def test_f16x3_scale_slots(dev, f16x3):
     """The training-loop protocol: persistent slots, primed once, then each call uses the maximum recorded by the
     previous iteration's kernels (ddmp_gemm_scales_roll).  Growth within the head-room (x 64) is exact business as
-    usual; growth beyond it is clamped and raises the slot's flag."""
+    usual; growth beyond it raises the slot's flag AND is healed on the spot: the same call re-launches the kernel,
+    which redoes the product with the maximum it has just measured (gemm_f16s.inc) -- the result the caller sees is the
+    float32-class one, the roll counts the event."""
     from dual_dmp_amd import ops
     n, K, M = 40000, 256, 256
     torch.manual_seed(6)
@@ -297,10 +299,44 @@ def test_f16x3_scale_slots(dev, f16x3):
     ops.gemm_next_scales(slots[1], slots[0])
     assert relerr(ops.gemm_tn(gg * 5, ag), 5 * (g.double().t() @ a.double())) < 3e-6
     assert int(slots[:, 2].view(torch.int32).abs().sum()) == 0
-    # beyond the head-room: flagged (and clamped, so the result is off)
+    # beyond the head-room (x 1000 between two iterations): flagged, healed, counted
+    ops.gemm_scales_roll(slots)
     ops.gemm_next_scales(slots[0], None)
-    ops.gemm_nt(ag * 1000.0, wg)
+    y = ops.gemm_nt(ag * 1000.0, wg)
     assert int(slots[0, 2].view(torch.int32)) == 1
+    assert relerr(y, ref * 1000.0) < 2e-6                          # NOT the clamped product
+    ops.gemm_next_scales(slots[1], slots[0])                        # the wgrad on the same (outgrown) operand slot
+    dw = ops.gemm_tn(gg, ag * 1000.0)
+    assert relerr(dw, 1000.0 * (g.double().t() @ a.double())) < 3e-6
+    ops.gemm_scales_roll(slots)
+    assert int(slots[0, 2].view(torch.int32)) == 0 and float(slots[0, 3]) == 1.0 and float(slots[1, 3]) == 0.0
+    assert float(slots[0, 0]) == float((a * 1000.0).abs().max())  # and the next iteration starts from the right scale
+    # the dgrad-with-BatchNorm-backward and statistics forms heal the same way
+    yb = torch.randn(n, M, device=dev)
+    bn4 = torch.stack([torch.rand(M) + 0.5, torch.randn(M), torch.randn(M), torch.rand(M) + 0.5]).to(dev)
+    c10 = torch.stack([torch.randn(M) * 0.1, torch.randn(M) * 0.1]).to(dev)
+    if ops.gemm_bnbwd_supported(M, K, n):
+        slot = torch.zeros(1, 4, device=dev)
+        ops.gemm_next_scales(slot[0], None, prime=True)
+        ops.gemm_nn_bnbwd(gg, yb, wg, bn4, c10)
+        ops.gemm_scales_roll(slot)
+        ops.gemm_next_scales(slot[0], None)
+        big = ops.gemm_nn_bnbwd(gg * 1e6, yb * 1e3, wg, bn4, c10)
+        dy = torch.empty(n, M, device=dev)
+        ops.bn_bwd_apply(gg * 1e6, yb * 1e3, bn4, c10, dy, torch.empty(2 * M, dtype=torch.float64, device=dev))
+        assert int(slot[0, 2].view(torch.int32)) == 1
+        assert relerr(big, dy.double().cpu() @ w.double()) < 3e-6
+    # a non-finite operand cannot be healed: the roll marks the slot -1
+    slot = torch.zeros(1, 4, device=dev)
+    ops.gemm_next_scales(slot[0], None, prime=True)
+    ops.gemm_nt(ag, wg)
+    ops.gemm_scales_roll(slot)
+    bad = ag.clone()
+    bad[5, 7] = float("inf")
+    ops.gemm_next_scales(slot[0], None)
+    ops.gemm_nt(bad, wg)
+    ops.gemm_scales_roll(slot)
+    assert float(slot[0, 3]) == -1.0
 
 
 def test_gemm_transpose_detecting(dev, gemm_mode):
