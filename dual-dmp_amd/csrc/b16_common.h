@@ -43,6 +43,23 @@ __device__ __forceinline__ void nt_st8b(bf16_t* p, uint4 v) {                   
     __builtin_nontemporal_store(o, reinterpret_cast<nt_u4*>(p));
 }
 
+// global -> LDS copy of 16 bytes per lane (LDS destination = wave-uniform base + lane * 16) issued from inline asm.
+// The builtin (__builtin_amdgcn_global_load_lds) is tracked by hipcc's waitcnt pass as a pending LDS write: every later
+// ds_read / ds_write it cannot prove disjoint from the destination -- any run-time LDS offset -- is preceded by a
+// vmcnt(0), i.e. a drain of the whole copy pipeline (measured: 2x on spmm_patch2_kernel).  From asm the copy is invisible
+// to that pass; the kernels that use it order their LDS reads behind the copies themselves: counted s_waitcnt vmcnt(N),
+// then s_barrier, then the reads (cdna_hip_programming.md §5.7).  M0 (the destination base) is saved and restored
+// inside the statement.
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+    const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_dst);
+    const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst_u)
+                 : "memory");
+}
+
 __host__ inline bool b16_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace ddmp

@@ -102,4 +102,11 @@ struct ddmp_graph {
     uint16_t* lcol;     // device [nnz]
     int max_patch;      // largest patch (0: tables not built)
 };
-namespace ddmp { constexpr int kChunkRows = 64; }
+namespace ddmp {
+constexpr int kChunkRows = 64;
+// LDS-patch SpMM (spmm_patch.hip), shared by the float32 and bfloat16 entry points: DDMP_OK / an error / "take the slab kernel"
+constexpr int kPatchNotApplicable = -100;
+int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
+               const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
+               const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st);
+}

@@ -113,8 +113,11 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
     for (int i = tid; i < MP; i += 512) s_bias[i] = (bias && i < MD) ? bias[i] : 0.f;
     __syncthreads();
 
-    // ---- A stream: global (bf16) -> registers -> [prologue] -> LDS image
-    const int aslot = tid & 3, ar = tid >> 2;                    // (16-byte slot of the 64-byte stage row, row): 128 rows / pass
+    // ---- A stream.  PM == 0: global -> LDS copies like W (16 rows x 64 bytes per wave instruction; the lane's SOURCE
+    // slot is pre-swizzled so that the lane-linear LDS image is the swizzled one), two stages ahead, no registers.
+    // PM == 1: global (bf16) -> registers (three stages ahead) -> prologue -> ds_write into the image.
+    const int aslot = PM ? (tid & 3) : ((lane & 3) ^ ((lane >> 4) & 3));      // 16-byte slot of the 64-byte stage row
+    const int ar = PM ? (tid >> 2) : (wave * 16 + (lane >> 2));               // row within a 128-row pass
     uint4 R[NB][NA];
     const bf16_t* aptr[NA];
     int lt = blockIdx.x, lk = 0;
@@ -124,6 +127,11 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
             const int64_t row = min(t * BMR + p * 128 + ar, n_rows - 1);
             aptr[p] = A + row * lda + aslot * 8;
         }
+    };
+    auto a_copy = [&](int buf) {                                 // PM == 0: the next stage -> buffer buf
+        __bf16* dst = As + buf * kAStage + wave * 16 * kBK;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) dma16(aptr[p] + lk, dst + p * 128 * kBK);
     };
     a_tile(lt);
     auto a_load = [&](uint4 (&r)[NA]) {
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
 #pragma unroll
         for (int c0 = 0; c0 < NCW; ++c0) {
             const int c = NCH >= 8 ? c0 * 8 + wave : wave % NCH;
-            __builtin_amdgcn_global_load_lds((const void*)(bsrc + c * 512), (void*)(dst + c * 512), 16, 0, 0);
+            dma16(bsrc + c * 512, dst + c * 512);
         }
         ++bk;
         const bool wrap = bk == ns;
@@ -242,15 +250,15 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
     // ring slot g % 3 <- A loads of stage g+3
     auto iteration = [&](int buf, int bufa, int bufw, uint4 (&rl)[NA], const uint4 (&rs)[NA]) {
         rd(buf, 0);
-        rd(buf, 1);
         __builtin_amdgcn_sched_barrier(0);
-        mm(0);
-        a_store(bufa, rs);
+        mm(0);                                                   // the second k-step's fragments arrive behind these MFMAs
+        rd(buf, 1);
+        if (PM) a_store(bufa, rs);
         __builtin_amdgcn_sched_barrier(0);
         mm(1);
         b_copy(bufw);
-        asm volatile("" ::: "memory");                           // the A loads stay BEHIND the W copies in the VMEM stream
-        a_load(rl);
+        asm volatile("" ::: "memory");                           // the A requests stay BEHIND the W copies in the VMEM stream
+        if (PM) a_load(rl); else a_copy(bufw);
         __builtin_amdgcn_sched_barrier(0);
         a_advance();
         stored = false;
@@ -264,13 +272,20 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
     };
     b_copy(0);
     b_copy(1);
-    a_load(R[0]);
-    a_advance();
-    a_load(R[1]);
-    a_advance();
-    a_load(R[2]);
-    a_advance();
-    a_store(0, R[0]);
+    if (PM) {
+        a_load(R[0]);
+        a_advance();
+        a_load(R[1]);
+        a_advance();
+        a_load(R[2]);
+        a_advance();
+        a_store(0, R[0]);
+    } else {
+        a_copy(0);
+        a_advance();
+        a_copy(1);
+        a_advance();
+    }
     wait_barrier<0>();
     for (int g = 0; g < G; g += 3) {
         iteration(0, 1, 2, R[0], R[1]);

@@ -732,6 +732,11 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
         spmm_mode = (e && e[0] == 'r') ? 0 : (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3
                     : (e && e[0] == 's' && e[1] == '1') ? 5 : 4;          // default: slab kernel, 32-channel slabs
     }
+    if (vec && spmm_mode >= 4) {                                 // LDS-patch kernel (spmm_patch.hip) where it applies
+        const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, st);
+        if (rc != ddmp::kPatchNotApplicable) return rc;
+    }
     if (vec && spmm_mode >= 4 && patch_ok(g, C))
         return launch_patch_dma<false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
     if (vec && spmm_mode >= 4 && C >= 32 && C % 32 == 0) {
@@ -816,6 +821,17 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnRed red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
+    {
+        const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift,
+                                        mean, rstd, (float*)ws, st);
+        if (rc == DDMP_OK) {
+            const size_t pb2 = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
+            fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pb2), sums2, st);
+            LAUNCH_TRY();
+            return DDMP_OK;
+        }
+        if (rc != ddmp::kPatchNotApplicable) return rc;
+    }
     if (patch_ok(g, C)) {
         int rc = launch_patch_dma<true>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
         if (rc != DDMP_OK) return rc;

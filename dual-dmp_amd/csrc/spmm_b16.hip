@@ -214,6 +214,11 @@ extern "C" int ddmp_spmm_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ld
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
     ARG_TRY(coef_ok(bias) && coef_ok(pro_scale) && coef_ok(pro_shift));
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, st);
+        if (rc != ddmp::kPatchNotApplicable) return rc;
+    }
     if (pro_scale) return dispatch_b16<true, false, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
     return dispatch_b16<false, false, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st);
 }
@@ -234,7 +239,10 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
     hipStream_t st = (hipStream_t)stream;
     const int n_chunks = (int)cdiv(g->n_rows, kRB);
     BnRedB red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
-    int rc = dispatch_b16<false, true, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
+    int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift, mean, rstd,
+                              (float*)ws, st);
+    if (rc == ddmp::kPatchNotApplicable)
+        rc = dispatch_b16<false, true, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);

@@ -1,0 +1,345 @@
+// GCN aggregation, LDS-patch form (float32 and bfloat16 features):  Y[i,:] = dinv[i] * sum_e dinv[col e] * f(X[col e,:]) (+ bias)
+//
+// Why a second SpMM kernel.  The slab kernel (spmm.hip / spmm_b16.hip) gathers every CSR entry through the vector L1.
+// Measured on it: time = HBM streaming time + (entries per row) x (a fixed cost per gathered 128-byte
+// line); the two do not overlap, and the vertex graph (7 entries per row) sits at 41-44 % of 8 TB/s where the face graph
+// (4 entries) reaches 57-59 %.  The L1 returns data in request order, so the 6 of 7 gathers that HIT occupy the window
+// of requests in flight while only the one that misses moves HBM bytes: the achievable miss-level parallelism is the
+// window divided by the entries per row.
+// Here the two kinds of traffic use different pipes:
+//   * the DISTINCT rows a 64-row chunk references (its "patch": 100-120 rows on a Morton-ordered mesh, 1.6-1.9 per
+//     output row instead of 4-7; tables built once per graph, graph.hip) are copied global -> LDS by
+//     global_load_lds_dwordx4, one 128-byte slab of 8 rows per wave instruction, no VGPRs: every request in the L1 window
+//     is a row fetch;
+//   * the gathers read the patch from LDS (ds_read_b128, 256 B/clk/CU) through the entries' patch-local indices.
+// What the first attempt at this (spmm_patch_dma_kernel, round 1: 2 buffers, a fifth wave copying one slab ahead, a
+// vmcnt(0) + barrier per slab) got wrong was depth: one 14 KB slab in flight per workgroup.  Here every wave issues its
+// share of the copies NB-1 slabs ahead (NB = 4 buffers), one barrier per slab, and the wait before it is a COUNTED
+// vmcnt that leaves the younger slabs' copies and the output stores in flight.  Nothing in the slab loop returns data to
+// a VGPR from memory: coefficients, dinv, CSR slice, patch list (and the Yp rows of the fused reduction) are in LDS, so
+// the in-order VMEM counter carries only copies and stores and can be counted exactly.
+#include "b16_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+using namespace ddmp;
+
+constexpr int kRB = 64;            // rows per chunk (= ddmp::kChunkRows: the patch tables are per 64 rows)
+constexpr int kMaxE = kRB * 16;    // CSR entries per chunk
+constexpr int kNB = 4;             // patch buffers (the exact-count prologue below is written for 4)
+
+template <typename T> struct Lane;                                  // one lane = 16 bytes of a row
+template <> struct Lane<float> {
+    static constexpr int VW = 4;
+    static __device__ __forceinline__ void unpack(uint4 u, float (&f)[4]) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&f)[4]) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Lane<bf16_t> {
+    static constexpr int VW = 8;
+    static __device__ __forceinline__ void unpack(uint4 u, float (&f)[8]) { bf_unpack8(u, f); }
+    static __device__ __forceinline__ uint4 pack(const float (&f)[8]) { return bf_pack8(f); }
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+struct RedArgs {                    // fused BatchNorm-backward column reductions of the output (see BnRed in spmm.hip)
+    const void* Yp;
+    int64_t ldyp;
+    const float *scale, *shift, *mean, *rstd;
+    float* part;
+};
+
+// KD: copies per wave and slab of the patch (8 rows each, 4 waves): the patch buffer holds 32 KD rows
+template <typename T, int KD, bool PRO, bool RED>
+__global__ __launch_bounds__(256) void spmm_patch2_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
+    const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
+    const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
+    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
+    int chunks_per_xcd, int n_chunks, RedArgs red) {
+    constexpr int VW = Lane<T>::VW, CS = 8 * VW;                 // channels per 128-byte slab
+    constexpr int PR = 32 * KD;                                  // patch rows per buffer
+    constexpr int KR = RED ? 2 : 0;                              // copies per wave and slab of the chunk's own Yp rows
+    constexpr int NST = 2;                                       // output stores per lane and slab
+    constexpr int kBuf = PR * 128 + (RED ? kRB * 128 : 0);       // bytes per buffer
+    constexpr int NWAIT = (KD + KR) * (kNB - 2) + NST * (kNB - 1);   // VMEM operations younger than the copies of slab s
+    static_assert(NWAIT <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* bufs = smem;                                  // [kNB][kBuf]
+    float* s_w = reinterpret_cast<float*>(smem + kNB * kBuf);    // [kMaxE]
+    float* s_dinv = s_w + kMaxE;                                 // [kRB]
+    int* s_rowptr = reinterpret_cast<int*>(s_dinv + kRB);        // [kRB + 1] (+3 pad)
+    int* s_pl = s_rowptr + kRB + 4;                              // [PR]
+    unsigned short* s_lc = reinterpret_cast<unsigned short*>(s_pl + PR);      // [kMaxE]
+    float* s_coef = reinterpret_cast<float*>(s_lc + kMaxE);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd
+
+    const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
+    if (chunk >= n_chunks) return;
+    const int r0 = chunk * kRB;
+    const int nr = min(kRB, n_rows - r0);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane >> 3, sl = lane & 7;
+
+    for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
+    for (int i = tid; i < nr; i += 256) s_dinv[i] = dinv[r0 + i];
+    const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
+    for (int i = tid; i < PR; i += 256) s_pl[i] = pl_col[p0 + min(i, np - 1)];      // padded with the last row
+    for (int i = tid; i < C; i += 256) {
+        s_coef[i] = bias ? bias[i] : 0.f;
+        if (PRO) {
+            s_coef[C + i] = pscale[i];
+            s_coef[2 * C + i] = pshift[i];
+        }
+        if (RED) {
+            s_coef[3 * C + i] = red.scale[i];
+            s_coef[4 * C + i] = red.shift[i];
+            s_coef[5 * C + i] = red.mean[i];
+            s_coef[6 * C + i] = red.rstd[i];
+        }
+    }
+    __syncthreads();
+    const int e0 = s_rowptr[0];
+    const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (dispatcher: max_row_nnz <= 16)
+    for (int t = tid; t < ne; t += 256) {
+        s_lc[t] = lcol[e0 + t];
+        s_w[t] = dinv[col[e0 + t]];
+    }
+    __syncthreads();                                             // (plain loads above: all waited for by now)
+
+    const int n_slabs = C / CS;
+    const T* xlane = X + sl * VW;
+    const T* yplane = RED ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
+    // copies of slab s into buffer b: wave w, instruction i covers patch rows (4 i + w) * 8 .. + 7
+    auto copy = [&](int s, unsigned char* dst) {
+#pragma unroll
+        for (int i = 0; i < KD; ++i) {
+            const int j0 = (4 * i + wave) * 8;
+            const int row = s_pl[j0 + grp];
+            dma16(xlane + (int64_t)row * ldx + s * CS, dst + j0 * 128);
+        }
+        if (RED) {
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                const int j0 = (4 * i + wave) * 8;                // own rows j0 .. j0 + 7 of the chunk
+                const int row = r0 + min(j0 + grp, nr - 1);
+                dma16(yplane + (int64_t)row * red.ldyp + s * CS, dst + PR * 128 + j0 * 128);
+            }
+        }
+    };
+    const bool full = nr == kRB;                                 // a ragged last chunk stores less: wait for everything
+
+    // The slab loop is unrolled over the four buffers with COMPILE-TIME buffer addresses: the compiler orders a ds_read
+    // behind every LDS-DMA it cannot prove disjoint (a run-time buffer index costs a vmcnt(0) -- a full drain -- before
+    // the first read of every slab; measured 2x on the whole kernel).
+    if (0 < n_slabs) copy(0, bufs);
+    if (1 < n_slabs) copy(1, bufs + kBuf);
+    if (2 < n_slabs) copy(2, bufs + 2 * kBuf);
+    auto slab = [&](int s, auto bc) {
+        constexpr int B = decltype(bc)::value;
+        // the copies of slab s have landed (mine: counted wait; everybody's: barrier); all waves are done with slab s-1
+        // (counted: the kNB-2 younger slabs' copies and the stores issued since stay in flight; the first kNB-1 slabs
+        //  have fewer stores behind them, the last ones fewer copies: exact counts or a full drain)
+        constexpr int ND = (KD + KR) * (kNB - 2);
+        if (!full || s + kNB - 1 > n_slabs) wait_vm_barrier<0>();
+        else if (s == 0) wait_vm_barrier<ND>();
+        else if (s == 1) wait_vm_barrier<ND + NST>();
+        else if (s == 2) wait_vm_barrier<ND + 2 * NST>();
+        else wait_vm_barrier<NWAIT>();
+        if (s + kNB - 1 < n_slabs) copy(s + kNB - 1, bufs + ((B + kNB - 1) % kNB) * kBuf);
+        const unsigned char* pb = bufs + B * kBuf + sl * 16;
+        const int off = s * CS + sl * VW;
+        float pa[VW], psh[VW], bs[VW];
+#pragma unroll
+        for (int q = 0; q < VW / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&s_coef[off + 4 * q]);
+            bs[4 * q] = t.x; bs[4 * q + 1] = t.y; bs[4 * q + 2] = t.z; bs[4 * q + 3] = t.w;
+            if (PRO) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_coef[C + off + 4 * q]);
+                const float4 c = *reinterpret_cast<const float4*>(&s_coef[2 * C + off + 4 * q]);
+                pa[4 * q] = a.x; pa[4 * q + 1] = a.y; pa[4 * q + 2] = a.z; pa[4 * q + 3] = a.w;
+                psh[4 * q] = c.x; psh[4 * q + 1] = c.y; psh[4 * q + 2] = c.z; psh[4 * q + 3] = c.w;
+            }
+        }
+        float q0[VW], q1[VW];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) q0[j] = q1[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int lr = wave * 8 + grp + 32 * q;
+            const bool on = lr < nr;
+            const int lrc = min(lr, nr - 1);
+            int es = s_rowptr[lrc] - e0;
+            const int ee = on ? s_rowptr[lrc + 1] - e0 : es;
+            float acc[VW];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+            while (es < ee) {
+                int li[4];
+                float wj[4];
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ek = min(es + k, ee - 1);
+                    li[k] = s_lc[ek];
+                    wj[k] = (es + k < ee) ? s_w[ek] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(pb + li[k] * 128);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t[VW];
+                    Lane<T>::unpack(v[k], t);
+#pragma unroll
+                    for (int j = 0; j < VW; ++j) {
+                        const float x = PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
+                        acc[j] = fmaf(wj[k], x, acc[j]);
+                    }
+                }
+                es += 4;
+            }
+            const float di = s_dinv[lrc];
+            float o[VW];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o[j] = fmaf(acc[j], di, bs[j]);
+            const uint4 ob = Lane<T>::pack(o);
+            if (on) {
+                typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+                nt_u4 ov = {ob.x, ob.y, ob.z, ob.w};
+                __builtin_nontemporal_store(ov, reinterpret_cast<nt_u4*>(Y + (int64_t)(r0 + lr) * ldy + off));
+            }
+            if (RED && on) {                                     // on the values as stored
+                float y[VW];
+                Lane<T>::unpack(ob, o);
+                Lane<T>::unpack(*reinterpret_cast<const uint4*>(pb + PR * 128 + lr * 128), y);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const float g = o[j] * lrelu_grad(fmaf(y[j], s_coef[3 * C + off + j], s_coef[4 * C + off + j]), slope);
+                    q0[j] += g;
+                    q1[j] = fmaf(g, (y[j] - s_coef[5 * C + off + j]) * s_coef[6 * C + off + j], q1[j]);
+                }
+            }
+        }
+        if (RED) {
+#pragma unroll
+            for (int j = 0; j < VW; ++j)
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    q0[j] += __shfl_xor(q0[j], o, 64);
+                    q1[j] += __shfl_xor(q1[j], o, 64);
+                }
+            if (grp == 0) {
+                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
+#pragma unroll
+                for (int q = 0; q < VW / 4; ++q) {
+                    *reinterpret_cast<float4*>(pp + 4 * q) = make_float4(q0[4 * q], q0[4 * q + 1], q0[4 * q + 2], q0[4 * q + 3]);
+                    *reinterpret_cast<float4*>(pp + C + 4 * q) = make_float4(q1[4 * q], q1[4 * q + 1], q1[4 * q + 2], q1[4 * q + 3]);
+                }
+            }
+        }
+    };
+    for (int s = 0; s < n_slabs; s += kNB) {
+        slab(s, std::integral_constant<int, 0>());
+        if (s + 1 < n_slabs) slab(s + 1, std::integral_constant<int, 1>());
+        if (s + 2 < n_slabs) slab(s + 2, std::integral_constant<int, 2>());
+        if (s + 3 < n_slabs) slab(s + 3, std::integral_constant<int, 3>());
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
+}
+
+template <typename T, int KD, bool PRO, bool RED>
+size_t patch2_lds(int C) {
+    const int PR = 32 * KD;
+    const size_t buf = (size_t)PR * 128 + (RED ? kRB * 128 : 0);
+    return kNB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4;
+}
+
+template <typename T, int KD, bool PRO, bool RED>
+int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
+                  const float* psh, float slope, hipStream_t st, RedArgs red) {
+    const int n = (int)g->n_rows;
+    const int n_chunks = (int)cdiv(n, kRB);
+    const int cpx = (int)cdiv(n_chunks, kXcd);
+    const size_t lds = patch2_lds<T, KD, PRO, RED>(C);
+    auto kern = spmm_patch2_kernel<T, KD, PRO, RED>;
+    static bool attr_done = false;                               // > 64 KB of dynamic LDS needs the attribute once per kernel
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->pl_ptr, g->pl_col, X,
+                       ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+template <typename T, bool PRO, bool RED>
+int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
+             const float* psh, float slope, hipStream_t st, RedArgs red) {
+    const int kd = (g->max_patch + 31) / 32;
+    switch (kd) {
+        case 1: case 2: case 3: return launch_patch2<T, 3, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+        case 4: return launch_patch2<T, 4, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+        case 5: return launch_patch2<T, 5, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+        case 6: return launch_patch2<T, 6, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+        default: return ddmp::kPatchNotApplicable;
+    }
+}
+
+// DDMP_SPMM_PATCH=1 selects this kernel (A/B runs).  OFF by default -- measured on MI355X, 1M-face mesh, Morton order,
+// C = 512 (scripts/microbench.py spmm): float32 face graph 1329 us vs 839 us for the slab kernel, vertex graph 911 vs
+// 592 us; bfloat16 860 vs 452 and 599 vs 332 us (1815 / 1118 us before the copies were hidden from hipcc's waitcnt pass,
+// b16_common.h dma16).  One workgroup of ~110 KB LDS per CU leaves the per-chunk set-up (CSR slice, patch list,
+// coefficients: two block-wide syncs) and the per-slab barrier exposed; at C = 64 the kernel is 2.8x slower.  The slab
+// kernels' 32 waves per CU hide more latency through the L1 than four waves do through LDS.
+int patch_mode() {
+    static int m = -1;
+    if (m < 0) {
+        const char* e = getenv("DDMP_SPMM_PATCH");
+        m = (e && atoi(e) == 1) ? 1 : 0;
+    }
+    return m;
+}
+
+}  // namespace
+
+namespace ddmp {
+
+// -> DDMP_OK, an error, or kPatchNotApplicable (the caller takes its slab kernel).  Needs the graph's patch tables, at most
+// 16 entries per row on average per chunk, C a multiple of the 128-byte slab and >= 2 slabs.
+int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
+               const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
+               const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st) {
+    if (!patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || g->max_row_nnz > kMaxE / kRB || !g->lcol) return kPatchNotApplicable;
+    const int cs = dtype == DDMP_BF16 ? 64 : 32;
+    if (C % cs != 0 || C < 2 * cs || C > 1024) return kPatchNotApplicable;
+    RedArgs red{red_Yp, red_ldyp, red_scale, red_shift, red_mean, red_rstd, red_part};
+    if (dtype == DDMP_BF16) {
+        auto x = static_cast<const bf16_t*>(X);
+        auto y = static_cast<bf16_t*>(Y);
+        if (red_part) return by_patch<bf16_t, false, true>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        if (ps) return by_patch<bf16_t, true, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        return by_patch<bf16_t, false, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    }
+    auto x = static_cast<const float*>(X);
+    auto y = static_cast<float*>(Y);
+    if (red_part) return by_patch<float, false, true>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    if (ps) return by_patch<float, true, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    return by_patch<float, false, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+}
+
+}  // namespace ddmp

@@ -12,9 +12,12 @@ ap.add_argument("what", nargs="?", default="all")
 ap.add_argument("--rows", type=int, default=1000000)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--order", default="native")
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = a.rows
+DT = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+ES = 2 if a.dtype == "bf16" else 4
 
 
 def timeit(fn, iters=a.iters):
@@ -55,16 +58,16 @@ if a.what in ("spmm", "all"):
     for gname, idx, nn_ in (("face", fi, len(f)), ("vert", ei, len(v))):
         g = ops.graph_for(idx, nn_)
         for C in (512, 256, 128, 64, 32):
-            X = torch.randn(nn_, C, device=dev); Y = torch.empty(nn_, C, device=dev)
+            X = torch.randn(nn_, C, device=dev).to(DT); Y = torch.empty(nn_, C, device=dev, dtype=DT)
             us = timeit(lambda: ops.spmm(g, X, out=Y))
-            alg = 2.0 * nn_ * C * 4 + 4.0 * g.nnz + 8.0 * nn_
+            alg = 2.0 * nn_ * C * ES + 4.0 * g.nnz + 8.0 * nn_
             print("spmm %s N=%d C=%3d  %8.0f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)  gather-logical %.1f GB/s" % (
                 gname, nn_, C, us, alg / us / 1e3, alg / us / 1e3 / 80.0, (g.nnz * C * 4.0 + nn_ * C * 4.0) / us / 1e3))
             if C >= 128:
                 sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev)
                 us_p = timeit(lambda: ops.spmm(g, X, out=Y, pro=(sc, sh)))
                 bn4 = torch.rand(4, C, device=dev) + 0.5; sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
-                Yp = torch.randn(nn_, C, device=dev)
+                Yp = torch.randn(nn_, C, device=dev).to(DT)
                 us_r = timeit(lambda: ops.spmm_bnred(g, X, Y, Yp, bn4, sums))
                 print("     +prologue %8.0f us (x%.2f)   +bn-backward reduce %8.0f us (x%.2f)" % (us_p, us_p / us, us_r, us_r / us))
 
