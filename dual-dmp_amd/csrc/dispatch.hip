@@ -121,3 +121,32 @@ extern "C" int ddmp_head_bwd(const void* Y, int64_t ldy, int64_t n, int dtype, c
                ? ddmp_head_bwd_bf16((cb)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, dout, (uint16_t*)dZ, lddz, dW1, db1, dW2, db2, ws, wsb, st)
                : ddmp_head_bwd_f32((cf)Y, ldy, n, scale, shift, slope, W1, b1, W2, b2, kind, dout, (float*)dZ, lddz, dW1, db1, dW2, db2, ws, wsb, st);
 }
+
+// ---- row gather / scatter for halo packing and node relabelling (16-byte pieces; rows of C elements, C * elt % 16 == 0)
+namespace {
+__global__ __launch_bounds__(256) void rows_gather_kernel(const uint4* __restrict__ src, int64_t ld16, const int64_t* __restrict__ idx,
+                                                          int64_t n, int q, uint4* __restrict__ dst, int64_t ldd16, int scatter) {
+    const int64_t total = n * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / q;
+        const int c = (int)(i - r * q);
+        const int64_t j = idx[r];
+        if (scatter) dst[j * ldd16 + c] = src[r * ld16 + c];
+        else dst[r * ldd16 + c] = src[j * ld16 + c];
+    }
+}
+}  // namespace
+
+extern "C" int ddmp_rows_gather(const void* src, int64_t ld_src, const int64_t* idx, int64_t n, int C, int dtype, void* dst,
+                                int64_t ld_dst, int scatter, ddmp_stream stream) {
+    ARG_TRY(src && idx && dst && n >= 0 && C > 0 && dt_ok(dtype));
+    const int es = dtype == DDMP_BF16 ? 2 : 4;
+    ARG_TRY((C * es) % 16 == 0 && (ld_src * es) % 16 == 0 && (ld_dst * es) % 16 == 0 && ld_src >= C && ld_dst >= C);
+    ARG_TRY(b16_aligned(src) && b16_aligned(dst));
+    if (n == 0) return DDMP_OK;
+    const int q = C * es / 16;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n * q, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)src, ld_src * es / 16, idx, n, q, (uint4*)dst, ld_dst * es / 16, scatter);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}

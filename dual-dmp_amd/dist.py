@@ -134,10 +134,16 @@ class GraphComm:
     def halo_exchange(self, t: torch.Tensor, n_rows: int):
         p = self.plan
         assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
-        send = t[:n_rows].index_select(0, self.send_idx)
+        send = self._pack(t, n_rows)
         recv = t[n_rows:p.n_cols]
         self.backend.all_to_all(recv, send, p.recv_counts, p.send_counts)
         return t
+
+    def _pack(self, t, n_rows):
+        """Boundary rows in plan order: the library's gather kernel on the GPU (ddmp_rows_gather), torch on the CPU stub."""
+        if t.is_cuda and (t.shape[1] * t.element_size()) % 16 == 0 and self.send_idx.numel() > 0:
+            return ops.rows_gather(t[:n_rows], self.send_idx)
+        return t[:n_rows].index_select(0, self.send_idx)
 
     def all_reduce_sum(self, t: torch.Tensor):
         return self.backend.all_reduce_sum(t)
@@ -146,7 +152,7 @@ class GraphComm:
     def start_halo(self, t: torch.Tensor, n_rows: int):
         p = self.plan
         assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
-        send = t[:n_rows].index_select(0, self.send_idx)
+        send = self._pack(t, n_rows)
         recv = t[n_rows:p.n_cols]
         start = getattr(self.backend, "all_to_all_start", None)
         if start is None:
@@ -220,6 +226,11 @@ class TorchDistComm:
     def all_reduce_start(self, t):
         return _Pending(self.dist.all_reduce(t, group=self.group, async_op=True), t)
 
+    def all_gather_rows(self, out, local):
+        """out [P * m, c] <- every rank's `local` [m, c] (equal shapes), rank-major."""
+        self.dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        return out
+
     def barrier(self):
         self.dist.barrier(group=self.group)
 
@@ -273,6 +284,19 @@ class ThreadComm:
         t.copy_(acc)
         return t
 
+    def all_gather_rows(self, out, local):
+        if local.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.slots[self.rank] = local
+        self.s.barrier.wait()
+        m = local.shape[0]
+        for r in range(self.world_size):
+            out[r * m:(r + 1) * m].copy_(self.s.slots[r])
+        if out.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.s.barrier.wait()
+        return out
+
     def barrier(self):
         self.s.barrier.wait()
 
@@ -282,15 +306,23 @@ def global_csr(edge_index: np.ndarray, n: int):
     return ops.csr_build_host(edge_index, n)
 
 
-class ShardedData:
-    """What a rank's two engines read: local slices of the static inputs + the two halo plans."""
+_global_tables = {}
+_global_lock = threading.Lock()
 
-    def __init__(self, dataset, n_mesh, rank: int, P: int, face_owner=None):
+
+def _shared_global_tables(dataset, n_mesh, P, face_owner):
+    """The rank-independent part of the partition (owners, the two global CSRs, Morton keys), built ONCE per process and
+    (dataset, P): logical ranks that live in one process (ThreadComm: tests, single-GPU emulation of an 8-way run) share
+    it instead of each repeating O(global mesh) numpy work; one process per GPU builds it once anyway."""
+    key = (id(dataset), id(n_mesh), P)
+    with _global_lock:
+        hit = _global_tables.get(key)
+        if hit is not None and hit[0] is dataset:
+            return hit[1]
         V, F = len(n_mesh.vs), len(n_mesh.faces)
         if face_owner is None:
             face_owner = face_owner_morton(n_mesh.fc, P)
-        self.face_owner = face_owner
-        self.vert_owner = vertex_owner_from_faces(n_mesh.faces, face_owner, V)
+        vert_owner = vertex_owner_from_faces(n_mesh.faces, face_owner, V)
         ei = dataset.edge_index.cpu().numpy()
         fi = dataset.face_index.cpu().numpy()
         # local row order = Morton rank of the node (smoothed vertex positions / noisy face centroids), the same
@@ -299,8 +331,35 @@ class ShardedData:
         vkey[morton_order(dataset.x_pos.detach().cpu().double().numpy())] = np.arange(V)
         fkey = np.empty(F, dtype=np.int64)
         fkey[morton_order(np.asarray(n_mesh.fc, dtype=np.float64))] = np.arange(F)
-        self.vplan = HaloPlan(*global_csr(ei, V), self.vert_owner, rank, P, order_key=vkey)
-        self.fplan = HaloPlan(*global_csr(fi, F), self.face_owner, rank, P, order_key=fkey)
+        # where every rank's owned rows (in its local order: increasing Morton key) go in the global arrays: the
+        # replicated losses are fed by ONE all-gather of the owned pos | norm rows, padded to the largest shard
+        vord, ford = np.lexsort((vkey, vert_owner)), np.lexsort((fkey, face_owner))
+        vcnt, fcnt = np.bincount(vert_owner, minlength=P), np.bincount(face_owner, minlength=P)
+        m = int((vcnt + fcnt).max())
+        gather_dst = np.full((P, m), V + F, dtype=np.int64)            # pads land in a scratch row behind the arrays
+        vo = np.concatenate([[0], np.cumsum(vcnt)])
+        fo = np.concatenate([[0], np.cumsum(fcnt)])
+        for r in range(P):
+            gather_dst[r, :vcnt[r]] = vord[vo[r]:vo[r + 1]]
+            gather_dst[r, vcnt[r]:vcnt[r] + fcnt[r]] = V + ford[fo[r]:fo[r + 1]]
+        tables = dict(face_owner=face_owner, vert_owner=vert_owner, vcsr=global_csr(ei, V), fcsr=global_csr(fi, F),
+                      vkey=vkey, fkey=fkey, gather_dst=gather_dst.reshape(-1), gather_rows=m)
+        if len(_global_tables) > 4:
+            _global_tables.clear()
+        _global_tables[key] = (dataset, tables)
+        return tables
+
+
+class ShardedData:
+    """What a rank's two engines read: local slices of the static inputs + the two halo plans."""
+
+    def __init__(self, dataset, n_mesh, rank: int, P: int, face_owner=None):
+        V, F = len(n_mesh.vs), len(n_mesh.faces)
+        g = _shared_global_tables(dataset, n_mesh, P, face_owner)
+        self.face_owner, self.vert_owner = g["face_owner"], g["vert_owner"]
+        self.vplan = HaloPlan(*g["vcsr"], self.vert_owner, rank, P, order_key=g["vkey"])
+        self.fplan = HaloPlan(*g["fcsr"], self.face_owner, rank, P, order_key=g["fkey"])
+        self.gather_dst, self.gather_rows = g["gather_dst"], g["gather_rows"]
         self.z1 = dataset.z1.detach().cpu()[torch.from_numpy(self.vplan.local_ids)]
         self.z2 = dataset.z2.detach().cpu()[torch.from_numpy(self.fplan.local_ids)]
         self.x_pos = dataset.x_pos.detach().cpu()[torch.from_numpy(self.vplan.owned)]
@@ -330,7 +389,10 @@ class DistributedTrainer:
         posnet._engine, normnet._engine = self.peng, self.neng
         self.owned_v = torch.from_numpy(sd.vplan.owned).to(device)
         self.owned_f = torch.from_numpy(sd.fplan.owned).to(device)
-        self.full = torch.zeros((sd.V + sd.F, 3), dtype=torch.float32, device=device)
+        self.full = torch.zeros((sd.V + sd.F + 1, 3), dtype=torch.float32, device=device)     # + the scratch row of the pads
+        self.gather_dst = torch.from_numpy(sd.gather_dst).to(device)
+        self.gather_send = torch.zeros((sd.gather_rows, 3), dtype=torch.float32, device=device)
+        self.gather_recv = torch.empty((backend.world_size * sd.gather_rows, 3), dtype=torch.float32, device=device)
         if loss_engine is None:
             from .loss import LossEngine
             loss_engine = LossEngine(n_mesh, device, bnfloop=bnfloop, k=k)
@@ -357,6 +419,9 @@ class DistributedTrainer:
     def gather_pos(self):
         return self.full[: self.sd.V]
 
+    def gather_norm(self):
+        return self.full[self.sd.V: self.sd.V + self.sd.F]
+
     def check_scales(self) -> int:
         return self.peng.check_scales() + self.neng.check_scales()
 
@@ -379,12 +444,15 @@ class DistributedTrainer:
         else:
             self.peng.forward(pa, update_running=True)
             self.neng.forward(na, update_running=True)
+        # the losses are replicated: ONE all-gather of every rank's owned pos | norm rows (padded to the largest shard),
+        # scattered to their global places (half the bytes of the zero-fill + all-reduce it replaces)
         pos_loc, norm_loc = self.peng.result, self.neng.result
-        self.full.zero_()
-        self.full[:V].index_copy_(0, self.owned_v, pos_loc)
-        self.full[V:].index_copy_(0, self.owned_f, norm_loc)
-        self.backend.all_reduce_sum(self.full)
-        pos, norm = self.full[:V], self.full[V:]
+        nv, nf = pos_loc.shape[0], norm_loc.shape[0]
+        self.gather_send[:nv].copy_(pos_loc)
+        self.gather_send[nv:nv + nf].copy_(norm_loc)
+        self.backend.all_gather_rows(self.gather_recv, self.gather_send)
+        self.full.index_copy_(0, self.gather_dst, self.gather_recv)
+        pos, norm = self.full[:V], self.full[V:V + self.sd.F]
         gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
         lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
         if self.interleaved:

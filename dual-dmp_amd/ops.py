@@ -400,6 +400,18 @@ def gemm_bnbwd_supported(cout, cin, n_rows, dtype=torch.float32):
     return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin), int(n_rows)))
 
 
+def rows_gather(src, idx, out=None, n_rows=None):
+    """out[r] = src[idx[r]] (halo packing on the library's kernel; float32 / bfloat16 rows of 16-byte multiples)."""
+    src, lds = _mat(src, "src")
+    n = idx.numel() if n_rows is None else n_rows
+    if out is None:
+        out = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+    out, ldo = _mat(out, "out", src)
+    check(_lib.lib().ddmp_rows_gather(_p(src), lds, _p(_chk(idx, torch.int64, "idx")), n, src.shape[1], _dt(src), _p(out), ldo, 0,
+                                      _stream()), "ddmp_rows_gather")
+    return out
+
+
 def to_bf16(src, dst=None):
     """float32 -> bfloat16 (round to nearest even) on the library's kernel."""
     src = _chk(src.contiguous(), torch.float32, "src")

@@ -339,6 +339,11 @@ int ddmp_head_bwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const flo
                        float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
                        const float* dout, uint16_t* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
                        void* workspace, size_t workspace_bytes, ddmp_stream stream);
+/* Multi-device halo packing (the reference is single-device, main.py:51): dst[r,:] = src[idx[r],:]
+ * (scatter = 0: the boundary rows a rank sends, in the order of its halo plan) or dst[idx[r],:] = src[r,:] (scatter = 1);
+ * idx int64 on the device; rows of C elements with C * element size a multiple of 16 bytes. */
+int ddmp_rows_gather(const void* src, int64_t ld_src, const int64_t* idx, int64_t n, int C, int dtype, void* dst,
+                     int64_t ld_dst, int scatter, ddmp_stream stream);
 /* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);

@@ -338,7 +338,8 @@ def test_bf16_engine_layer_by_layer_against_rounding_emulation(dev, oracle):
             got = eng.Y[l].cpu().double()
             ulp = 2.0 ** (torch.floor(torch.log2(torch.maximum(Y.abs(), got.abs()).clamp_min(1e-30))) - 7)    # bf16: 8 significant bits
             d = (got - Y).abs()
-            assert bool((d <= 1.001 * ulp).all()), (l, float((d / ulp).max()))
+            atol = 3e-6 * float(Y.abs().max())                   # float32 accumulation noise (elements that nearly cancel)
+            assert bool((d <= 1.001 * ulp + atol).all()), (l, float(((d - atol) / ulp).max()))
             frac = float((d > 0).double().mean())
             worst_frac = max(worst_frac, frac)
             # BatchNorm coefficients from the stored values
