@@ -292,6 +292,7 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")           # (single-process DDMP_FORCE_DIST runs have no launcher)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def make_trainer(noisy, smooth, data):

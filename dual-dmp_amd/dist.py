@@ -134,6 +134,9 @@ class GraphComm:
     def halo_exchange(self, t: torch.Tensor, n_rows: int):
         p = self.plan
         assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
+        native = getattr(self.backend, "halo_exchange_native", None)
+        if native is not None:                                  # pack + grouped send/recv from C (csrc/comm.hip)
+            return native(p, t)
         send = self._pack(t, n_rows)
         recv = t[n_rows:p.n_cols]
         self.backend.all_to_all(recv, send, p.recv_counts, p.send_counts)
@@ -152,6 +155,10 @@ class GraphComm:
     def start_halo(self, t: torch.Tensor, n_rows: int):
         p = self.plan
         assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
+        native = getattr(self.backend, "halo_exchange_native", None)
+        if native is not None:                                  # stream-ordered: nothing to wait for on the host
+            native(p, t)
+            return None
         send = self._pack(t, n_rows)
         recv = t[n_rows:p.n_cols]
         start = getattr(self.backend, "all_to_all_start", None)
@@ -159,6 +166,15 @@ class GraphComm:
             self.backend.all_to_all(recv, send, p.recv_counts, p.send_counts)
             return None
         return start(recv, send, p.recv_counts, p.send_counts)
+
+    def halo_and_sums(self, t: torch.Tensor, n_rows: int, sums: torch.Tensor) -> bool:
+        """The halo rows of `t` and the all-reduce of the BatchNorm column sums in ONE grouped RCCL launch (native
+        backend only; False = not available, the caller issues the two collectives separately)."""
+        native = getattr(self.backend, "halo_exchange_native", None)
+        if native is None:
+            return False
+        native(self.plan, t, sums)
+        return True
 
     def start_all_reduce(self, t: torch.Tensor):
         start = getattr(self.backend, "all_reduce_start", None)
@@ -233,6 +249,75 @@ class TorchDistComm:
 
     def barrier(self):
         self.dist.barrier(group=self.group)
+
+
+class NativeComm:
+    """RCCL through the library's OWN communicator and halo plans (csrc/comm.hip, include/ddmp_hip.h "Communicator +
+    halo plan + exchange"): the pack kernel, the grouped ncclSend/ncclRecv that lands halo rows in place and the
+    BatchNorm-sum all-reduce are enqueued from C on the caller's stream -- no Python collective objects, capturable.
+    torch.distributed is only the bootstrap channel (the 128-byte unique id) and the barrier.  Opt-in
+    (DDMP_DIST_NATIVE=1): no multi-GPU box exists in the build loop, it has run at world size 1 only."""
+
+    def __init__(self, device):
+        import ctypes
+        import torch.distributed as dist
+        from . import _lib
+        self.dist, self.L, self.ct = dist, _lib.lib(), ctypes
+        self.world_size, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device = torch.device(device)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(self.L.ddmp_comm_unique_id(buf), "ddmp_comm_unique_id")
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0)
+        h = ctypes.c_void_p()
+        with ops.on_device(self.device):
+            _lib.check(self.L.ddmp_comm_create(self.rank, self.world_size, ctypes.c_char_p(box[0]), ctypes.byref(h)), "ddmp_comm_create")
+        self.h = h
+        self._plans = {}
+
+    def plan_handle(self, plan: "HaloPlan"):
+        key = id(plan)
+        if key not in self._plans:
+            ct = self.ct
+            idx = np.ascontiguousarray(plan.send_idx, dtype=np.int64)
+            sc = np.asarray(plan.send_counts, dtype=np.int64)
+            rc = np.asarray(plan.recv_counts, dtype=np.int64)
+            h = ct.c_void_p()
+            with ops.on_device(self.device):
+                _lib_check(self.L.ddmp_halo_plan_create(self.world_size, self.rank, plan.n_rows, plan.n_cols, idx.ctypes.data,
+                                                        sc.ctypes.data, rc.ctypes.data, ct.byref(h)), "ddmp_halo_plan_create")
+            self._plans[key] = (h, plan)
+        return self._plans[key][0]
+
+    def halo_exchange_native(self, plan, t, sums=None):
+        h = self.plan_handle(plan)
+        dt = ops._dt(t)
+        ws = ops.Workspace.get(self.L.ddmp_halo_pack_bytes(h, t.shape[1], dt), t.device)
+        _lib_check(self.L.ddmp_halo_exchange(self.h, h, ops._p(t), t.stride(0), t.shape[1], dt, ops._p(ws), ws.numel(),
+                                             ops._p(sums), 0 if sums is None else sums.numel(), ops._stream()), "ddmp_halo_exchange")
+        return t
+
+    def all_reduce_sum(self, t):
+        assert t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
+        _lib_check(self.L.ddmp_comm_allreduce_sum(self.h, ops._p(t), t.numel(), 1 if t.dtype == torch.float64 else 0, ops._stream()),
+                   "ddmp_comm_allreduce_sum")
+        return t
+
+    def all_gather_rows(self, out, local):
+        local = local.contiguous()
+        _lib_check(self.L.ddmp_comm_allgather(self.h, ops._p(local), ops._p(out), local.numel() * local.element_size(), ops._stream()),
+                   "ddmp_comm_allgather")
+        return out
+
+    def barrier(self):
+        torch.cuda.synchronize(self.device)
+        self.dist.barrier()
+
+
+def _lib_check(st, what):
+    from . import _lib
+    _lib.check(st, what)
 
 
 class ThreadComm:
@@ -474,7 +559,10 @@ class DistributedTrainer:
 
 def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnfloop=1, backend=None, nets=None, **kw):
     from .networks import PosNet, NormalNet
-    backend = backend or TorchDistComm()
+    if backend is None:
+        import os
+        native = os.environ.get("DDMP_DIST_NATIVE") == "1" and torch.device(device).type == "cuda"
+        backend = NativeComm(device) if native else TorchDistComm()
     if nets is None:
         torch.manual_seed(0)                   # identical initial parameters on every rank
         nets = (PosNet(device), NormalNet(device))

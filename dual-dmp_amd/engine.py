@@ -308,10 +308,14 @@ class GcnEngine:
                 ops.bn_stats(Y, sums=self.sums, n_rows=n)
             # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
             # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
-            h_stats = comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
             halo_started = l < 11 and self.agg_first[l + 1]
-            h_halo = comm.start_halo(Y, n) if halo_started else None
-            yield _Both(h_stats, h_halo)
+            fused = getattr(comm, "halo_and_sums", None)
+            if halo_started and fused is not None and fused(Y, n, self.sums[: 2 * L.cout[l]]):
+                yield None                                       # one grouped launch carried both (native RCCL backend)
+            else:
+                h_stats = comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
+                h_halo = comm.start_halo(Y, n) if halo_started else None
+                yield _Both(h_stats, h_halo)
             ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
                            self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
             X, pro = Y, (self.bn4[l][0], self.bn4[l][1])

@@ -344,6 +344,28 @@ int ddmp_head_bwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const flo
  * idx int64 on the device; rows of C elements with C * element size a multiple of 16 bytes. */
 int ddmp_rows_gather(const void* src, int64_t ld_src, const int64_t* idx, int64_t n, int C, int dtype, void* dst,
                      int64_t ld_dst, int scatter, ddmp_stream stream);
+/* Communicator + halo plan + exchange on the caller's stream (csrc/comm.hip): one process per GPU, RCCL over xGMI.
+ *   ddmp_comm_unique_id    rank 0 draws the 128-byte id, the host side distributes it (any out-of-band channel)
+ *   ddmp_comm_create       ncclCommInitRank; status 1000 + ncclResult_t on RCCL errors
+ *   ddmp_halo_plan_create  send_idx_host [sum send_counts]: LOCAL owned row of every boundary row, grouped by destination
+ *                          rank in the order the receiver stores its halo; recv_counts per source rank (sum = n_cols - n_rows)
+ *   ddmp_halo_exchange     rows [0, n_rows) of T are owned, rows [n_rows, n_cols) the halo (grouped by source rank): packs the
+ *                          boundary rows (kernel), then ONE ncclGroup of send/recv pairs that lands the halo rows in place
+ *                          (ld == C) and, when sums != NULL, the all-reduce of `n_sums` float64 BatchNorm column sums
+ *   ddmp_comm_allreduce_sum / ddmp_comm_allgather   gradient arena, loss inputs */
+typedef struct ddmp_comm ddmp_comm;
+typedef struct ddmp_halo_plan ddmp_halo_plan;
+int ddmp_comm_unique_id(char* id128_host);
+int ddmp_comm_create(int rank, int world, const char* id128_host, ddmp_comm** out);
+int ddmp_comm_destroy(ddmp_comm* comm);
+int ddmp_halo_plan_create(int world, int rank, int64_t n_rows, int64_t n_cols, const int64_t* send_idx_host,
+                          const int64_t* send_counts_host, const int64_t* recv_counts_host, ddmp_halo_plan** out);
+int ddmp_halo_plan_destroy(ddmp_halo_plan* plan);
+size_t ddmp_halo_pack_bytes(const ddmp_halo_plan* plan, int C, int dtype);
+int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* plan, void* T, int64_t ld, int C, int dtype, void* pack_ws,
+                       size_t ws_bytes, double* sums /*nullable*/, int n_sums, ddmp_stream stream);
+int ddmp_comm_allreduce_sum(ddmp_comm* comm, void* buf, int64_t n, int is_f64, ddmp_stream stream);
+int ddmp_comm_allgather(ddmp_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, ddmp_stream stream);
 /* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
