@@ -10,6 +10,7 @@
 #include "b16_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -30,15 +31,47 @@ struct BnBwdGatherB {              // see BnBwdGather in spmm.hip
     const float *c1, *c0;
 };
 
-// LANES lanes x 8 channels per row and slab (LANES = 8: 128-byte slabs; 4 | 2 | 1 for C = 32 | 16 | 8)
-template <int LANES, int U, bool PRO, bool RED, bool BWD>
+// one lane = VW channels: 16 bytes (VW = 8) or 8 bytes (VW = 4) of a row
+template <int VW> struct Piece;
+template <> struct Piece<8> {
+    typedef uint4 raw;
+    static __device__ __forceinline__ raw ld(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+    static __device__ __forceinline__ void unpack(raw u, float (&f)[8]) { bf_unpack8(u, f); }
+    static __device__ __forceinline__ raw pack(const float (&f)[8]) { return bf_pack8(f); }
+    static __device__ __forceinline__ void st(bf16_t* p, raw v) { nt_st8b(p, v); }
+};
+template <> struct Piece<4> {
+    typedef uint2 raw;
+    static __device__ __forceinline__ raw ld(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ void unpack(raw u, float (&f)[4]) {
+        f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
+    }
+    static __device__ __forceinline__ raw pack(const float (&f)[4]) { return make_uint2(bf_pack(f[0], f[1]), bf_pack(f[2], f[3])); }
+    static __device__ __forceinline__ void st(bf16_t* p, raw v) {
+        typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+        nt_u2 o = {v.x, v.y};
+        __builtin_nontemporal_store(o, reinterpret_cast<nt_u2*>(p));
+    }
+};
+template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f)[VW]) {
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+        f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+    }
+}
+
+// LANES lanes x VW channels per row and slab (128-byte slabs: LANES x VW = 64; narrower rows: fewer lanes).
+// VW = 8 (16-byte pieces) by default; VW = 4 exists for A/B runs of the fused forms (see dispatch_b16).
+template <int VW, int LANES, int U, bool PRO, bool RED, bool BWD>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope, int chunks_per_xcd, int n_chunks, BnRedB red, BnBwdGatherB bwd) {
     static_assert(!BWD || (PRO && !RED), "BWD: the coefficients a, b come as the prologue's");
-    constexpr int CS = LANES * 8;
+    typedef Piece<VW> PC;
+    constexpr int CS = LANES * VW;
     constexpr int RPW = 64 / LANES;
     constexpr int RPB = 4 * RPW;
     __shared__ int s_rowptr[kRB + 1];
@@ -67,37 +100,36 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LANES, sl = lane % LANES;
     for (int c0 = 0; c0 < C; c0 += CS) {
-        const int off = c0 + sl * 8;
-        float pa[8], pb[8], bs[8], k1[8], k0[8];
-        float ra[8], rb[8], rmu[8], rrs[8], q0[8], q1[8];
+        const int off = c0 + sl * VW;
+        float pa[VW], pb[VW], k1[VW], k0[VW];
+        float ra[VW], rb[VW], rmu[VW], rrs[VW], q0[VW], q1[VW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            pa[j] = 1.f; pb[j] = 0.f; bs[j] = 0.f; k1[j] = 0.f; k0[j] = 0.f;
+        for (int j = 0; j < VW; ++j) {
+            pa[j] = 1.f; pb[j] = 0.f; k1[j] = 0.f; k0[j] = 0.f;
             q0[j] = 0.f; q1[j] = 0.f;
         }
         if (PRO) {
-            ld8f(pscale + off, pa);
-            ld8f(pshift + off, pb);
+            ldcf<VW>(pscale + off, pa);
+            ldcf<VW>(pshift + off, pb);
         }
-        if (bias) ld8f(bias + off, bs);
         if (BWD) {
-            ld8f(bwd.c1 + off, k1);
-            ld8f(bwd.c0 + off, k0);
+            ldcf<VW>(bwd.c1 + off, k1);
+            ldcf<VW>(bwd.c0 + off, k0);
         }
         if (RED) {
-            ld8f(red.scale + off, ra);
-            ld8f(red.shift + off, rb);
-            ld8f(red.mean + off, rmu);
-            ld8f(red.rstd + off, rrs);
+            ldcf<VW>(red.scale + off, ra);
+            ldcf<VW>(red.shift + off, rb);
+            ldcf<VW>(red.mean + off, rmu);
+            ldcf<VW>(red.rstd + off, rrs);
         }
         const bf16_t* xc = X + off;
         const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
         for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
             int es = s_rowptr[lr] - e0;
             const int ee = s_rowptr[lr + 1] - e0;
-            float acc[8];
+            float acc[VW];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int j = 0; j < VW; ++j) acc[j] = 0.f;
             while (es < ee) {
                 int cj[U];
                 float wj[U];
@@ -113,44 +145,47 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                     }
                     if (es + k >= ee) wj[k] = 0.f;
                 }
-                uint4 v[U], vy[BWD ? U : 1];
+                typename PC::raw v[U], vy[BWD ? U : 1];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    v[k] = ld8b(xc + (int64_t)cj[k] * ldx);
-                    if (BWD) vy[BWD ? k : 0] = ld8b(yc + (int64_t)cj[k] * bwd.ldyb);
+                    v[k] = PC::ld(xc + (int64_t)cj[k] * ldx);
+                    if (BWD) vy[BWD ? k : 0] = PC::ld(yc + (int64_t)cj[k] * bwd.ldyb);
                 }
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
-                    float t[8];
-                    bf_unpack8(v[k], t);
+                    float t[VW];
+                    PC::unpack(v[k], t);
                     if (BWD) {
-                        float y[8];
-                        bf_unpack8(vy[BWD ? k : 0], y);
+                        float y[VW];
+                        PC::unpack(vy[BWD ? k : 0], y);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
+                        for (int j = 0; j < VW; ++j)
                             t[j] = fmaf(pa[j], t[j] * lrelu_grad(fmaf(y[j], pa[j], pb[j]), slope), fmaf(k1[j], y[j], k0[j]));
                     } else if (PRO) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) t[j] = lrelu(fmaf(t[j], pa[j], pb[j]), slope);
+                        for (int j = 0; j < VW; ++j) t[j] = lrelu(fmaf(t[j], pa[j], pb[j]), slope);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(wj[k], t[j], acc[j]);
+                    for (int j = 0; j < VW; ++j) acc[j] = fmaf(wj[k], t[j], acc[j]);
                 }
                 es += U;
             }
             const int row = r0 + lr;
             const float di = dinv[row];
-            float o[8];
+            float o[VW], bs[VW];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fmaf(acc[j], di, bs[j]);
-            const uint4 ob = bf_pack8(o);
-            nt_st8b(Y + (int64_t)row * ldy + off, ob);
+            for (int j = 0; j < VW; ++j) bs[j] = 0.f;
+            if (bias) ldcf<VW>(bias + off, bs);                  // (per row, from the L1: not worth registers across the loop)
+#pragma unroll
+            for (int j = 0; j < VW; ++j) o[j] = fmaf(acc[j], di, bs[j]);
+            const typename PC::raw ob = PC::pack(o);
+            PC::st(Y + (int64_t)row * ldy + off, ob);
             if (RED) {                                           // on the values as stored (rounded)
-                float y[8];
-                bf_unpack8(ob, o);
-                bf_unpack8(ld8b(red.Yp + (int64_t)row * red.ldyp + off), y);
+                float y[VW];
+                PC::unpack(ob, o);
+                PC::unpack(PC::ld(red.Yp + (int64_t)row * red.ldyp + off), y);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < VW; ++j) {
                     const float g = o[j] * lrelu_grad(fmaf(y[j], ra[j], rb[j]), slope);
                     q0[j] += g;
                     q1[j] = fmaf(g, (y[j] - rmu[j]) * rrs[j], q1[j]);
@@ -159,7 +194,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         }
         if (RED) {                                               // per wave and chunk: one partial per channel
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < VW; ++j)
 #pragma unroll
                 for (int o = LANES; o < 64; o <<= 1) {
                     q0[j] += __shfl_xor(q0[j], o, 64);
@@ -167,10 +202,11 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 }
             if (grp == 0) {
                 float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
-                *reinterpret_cast<float4*>(pp) = make_float4(q0[0], q0[1], q0[2], q0[3]);
-                *reinterpret_cast<float4*>(pp + 4) = make_float4(q0[4], q0[5], q0[6], q0[7]);
-                *reinterpret_cast<float4*>(pp + C) = make_float4(q1[0], q1[1], q1[2], q1[3]);
-                *reinterpret_cast<float4*>(pp + C + 4) = make_float4(q1[4], q1[5], q1[6], q1[7]);
+#pragma unroll
+                for (int q = 0; q < VW / 4; ++q) {
+                    *reinterpret_cast<float4*>(pp + 4 * q) = make_float4(q0[4 * q], q0[4 * q + 1], q0[4 * q + 2], q0[4 * q + 3]);
+                    *reinterpret_cast<float4*>(pp + C + 4 * q) = make_float4(q1[4 * q], q1[4 * q + 1], q1[4 * q + 2], q1[4 * q + 3]);
+                }
             }
         }
     }
@@ -178,13 +214,13 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
 
 #include "fpartials.inc"
 
-template <int LANES, bool PRO, bool RED, bool BWD>
+template <int VW, int LANES, bool PRO, bool RED, bool BWD>
 int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red, BnBwdGatherB bwd) {
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
-    hipLaunchKernelGGL((spmm_slab_b16_kernel<LANES, 4, PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
+    hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
                        g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -194,10 +230,26 @@ template <bool PRO, bool RED, bool BWD>
 int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                  const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red = BnRedB(),
                  BnBwdGatherB bwd = BnBwdGatherB()) {
-    if (C % 64 == 0) return launch_b16<8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    if (C % 32 == 0) return launch_b16<4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    if (C % 16 == 0) return launch_b16<2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    return launch_b16<1, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    // DDMP_SPMM_B16_VW=4 (A/B): 8-byte pieces in the fused forms.  Measured SLOWER although it restores full occupancy
+    // (1M-face graph, C = 512: prologue form 771 vs 613 us, reduction form 1043 vs 999 us): these forms are bound by
+    // instructions issued per gathered byte (index / weight reads, 64-bit addresses, unpack + 4 VALU per element), and
+    // halving the piece doubles the per-gather part.
+    static int vw_fused = -1;
+    if (vw_fused < 0) {
+        const char* e = getenv("DDMP_SPMM_B16_VW");
+        vw_fused = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    constexpr bool kFused = PRO || RED || BWD;
+    if (kFused && vw_fused == 4) {
+        if (C % 64 == 0) return launch_b16<4, 16, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+        if (C % 32 == 0) return launch_b16<4, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+        if (C % 16 == 0) return launch_b16<4, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+        return launch_b16<4, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    }
+    if (C % 64 == 0) return launch_b16<8, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    if (C % 32 == 0) return launch_b16<8, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    if (C % 16 == 0) return launch_b16<8, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    return launch_b16<8, 1, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
 }
 
 bool shape_ok(const void* X, int64_t ldx, const void* Y, int64_t ldy, int C) {

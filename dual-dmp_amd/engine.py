@@ -187,9 +187,13 @@ class GcnEngine:
                            and supported(L.cout[l], L.cin_p[l], self.n_rows) for l in range(12)]
         # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
         # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
+        # bf16 features: rebuilding dY on the gather reads two rows per CSR entry; measured (scripts/microbench.py spmm
+        # --dtype bf16, 1M faces) it beats bn_bwd_apply + plain gather on the face graph (4 entries per row: 511 vs 554 us
+        # at C = 256) and loses on the vertex graph (7 entries: 386 vs 321 us)
         gather_ok = getattr(ops, "spmm_bnbwd_supported", None)
+        few_entries = dtype == torch.float32 or getattr(graph, "max_row_nnz", 99) <= 4
         self.fuse_gather_bwd = [bool(gather_ok) and isinstance(self.comm, NoComm) and not self.agg_first[l] and l > 0
-                                and gather_ok(L.cout[l]) and os.environ.get("DDMP_SPMM_BNBWD", "1") != "0"
+                                and gather_ok(L.cout[l]) and few_entries and os.environ.get("DDMP_SPMM_BNBWD", "1") != "0"
                                 for l in range(12)]
         cmax = max(L.cout)
         nc = self.n_cols
@@ -380,7 +384,10 @@ class GcnEngine:
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
                      L.view(grads, "linear2.weight"), L.view(grads, "linear2.bias"), n_rows=n)
         have_sums = False
-        fuse_red = hasattr(ops, "spmm_bnred")
+        # the backward column reductions from the SpMM epilogue: float32 features only.  With bf16 features the epilogue
+        # (one more row stream + 16 cross-lane sums per 128-byte slab) costs more than the separate pass it replaces
+        # (1M-face graph, C = 512: 939 us fused vs 457 + 390 us)
+        fuse_red = hasattr(ops, "spmm_bnred") and self.dtype == torch.float32
 
         def spmm_to_dz(src, dst, l):
             """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""

@@ -172,6 +172,9 @@ class Graph:
         self._h = handle
         self.n_rows, self.n_cols, self.nnz = n_rows, n_cols, nnz
         self._fin = weakref.finalize(self, _lib.lib().ddmp_graph_destroy, handle)
+        a, b, c, d = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        check(_lib.lib().ddmp_graph_info(handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)), "ddmp_graph_info")
+        self.max_row_nnz = int(d.value)                         # entries of the longest row (self loop included)
 
     @property
     def handle(self):

@@ -69,7 +69,13 @@ if a.what in ("spmm", "all"):
                 bn4 = torch.rand(4, C, device=dev) + 0.5; sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
                 Yp = torch.randn(nn_, C, device=dev).to(DT)
                 us_r = timeit(lambda: ops.spmm_bnred(g, X, Y, Yp, bn4, sums))
-                print("     +prologue %8.0f us (x%.2f)   +bn-backward reduce %8.0f us (x%.2f)" % (us_p, us_p / us, us_r, us_r / us))
+                c10 = torch.rand(2, C, device=dev) * 0.1
+                us_b = timeit(lambda: ops.spmm_bnbwd(g, X, Yp, bn4, c10, Y))
+                dY = torch.empty_like(X)
+                us_a = timeit(lambda: ops.bn_bwd_apply(X, Yp, bn4, c10, dY, sums))
+                us_s = timeit(lambda: ops.bn_bwd_reduce(X, Yp, bn4, sums2=sums))
+                print("     +prologue %8.0f us (x%.2f)   +bn-backward reduce %8.0f us (x%.2f; separate pass %.0f us)   "
+                      "bn-backward on the gather %8.0f us (apply pass %.0f us + plain)" % (us_p, us_p / us, us_r, us_r / us, us_s, us_b, us_a))
 
 if a.what in ("bn", "all"):
     for C in (512, 256):
