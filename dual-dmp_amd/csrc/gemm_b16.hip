@@ -24,6 +24,7 @@
 #include "b16_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -484,6 +485,131 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
     }
 }
 
+
+// The same wgrad with both operands as they are in HBM (no prologue: the agg-first layers, dW = dY^T . P, and every wgrad
+// whose Z is already activated): no registers on the way -- G and Z stages go global -> LDS by DMA (2 rows x 512 bytes per
+// wave instruction; the SOURCE 64-byte chunk is pre-swizzled by row & 3, so the lane-linear LDS image is the swizzled one
+// the transpose reads expect), three buffers, copies two stages ahead, one counted-vmcnt barrier per stage.  Every wave
+// issues the same four copies per stage whatever the shape (columns beyond M / K and rows beyond the split are CLAMPED to
+// valid addresses: harmless duplicates), so the in-order VMEM counter can be counted; the one ragged stage of the last
+// split zeroes its surplus G rows in LDS after they have landed.
+__global__ __launch_bounds__(512) void gemm_tn_b16_dma_kernel(
+    const bf16_t* __restrict__ G, int64_t ldg, const bf16_t* __restrict__ Z, int64_t ldz, float* __restrict__ out,
+    int64_t ld_out, int64_t split_stride, int n_rows, int M, int K, int rows_per_split, int n_tiles_m, int n_tiles_k,
+    int n_splits) {
+    constexpr int kStage = kBK * kTT;                            // elements of one operand stage (16 KB)
+    constexpr int NV = 4;                                        // copies per wave and stage
+    __shared__ __attribute__((aligned(16))) __bf16 smem[3 * 2 * kStage];
+
+    const int n_tiles = n_tiles_m * n_tiles_k;
+    const int xcd = blockIdx.x & (kXcd - 1), local = blockIdx.x >> 3;
+    const int tile = local % n_tiles;
+    const int split = (local / n_tiles) * kXcd + xcd;
+    if (split >= n_splits) return;
+    const int tm0 = (tile / n_tiles_k) * kTT, tk0 = (tile % n_tiles_k) * kTT;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(n_rows, r_begin + rows_per_split);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    // copy role: instruction q = 8 i + wave covers stage rows 2q, 2q+1; lane -> (row 2q + (lane >> 5), 16-byte piece lane & 31)
+    const int piece = lane & 31;
+    int64_t goff[2], zoff[2];
+    int crow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 2 * (8 * i + wave) + (lane >> 5);
+        const int col = ((((piece >> 2) ^ (r & 3)) << 2) | (piece & 3)) * 8;      // logical column of this lane's piece
+        crow[i] = r;
+        goff[i] = min(tm0 + col, M - 8);
+        zoff[i] = min(tk0 + col, K - 8);
+    }
+    auto copy = [&](int r0, __bf16* buf) {                       // stage rows r0 .. r0 + 31 -> buf (G image, then Z image)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = min(r0 + crow[i], r_end - 1);
+            dma16(G + row * ldg + goff[i], buf + (8 * i + wave) * 512);
+            dma16(Z + row * ldz + zoff[i], buf + kStage + (8 * i + wave) * 512);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int L = lane & 15, gi = (lane >> 4) & 1;
+    const bool wave_on = (tm0 + wr * 64 < M) && (tk0 + wc * 128 < K);
+    auto frag = [&](const __bf16* img, int cbase, int ks) -> bf16x8 {
+        const int nb = ks * 16 + lh * 8;
+        const int col = cbase + 16 * gi + 4 * (L & 3);
+        typedef __attribute__((address_space(3))) bf16x4* lp;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(img + tn_off(nb + (L >> 2), col)));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(img + tn_off(nb + 4 + (L >> 2), col)));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+    };
+    auto compute = [&](const __bf16* buf) {
+        if (!wave_on) return;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag(buf, wr * 64 + i * 32, ks);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = frag(buf + kStage, wc * 128 + j * 32, ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_b16(af[i], bf[j], acc[i][j]);
+        }
+    };
+    const int ns = (r_end - r_begin + kBK - 1) / kBK;
+    auto stage = [&](int s, __bf16* cur, __bf16* nxt2) {
+        copy(r_begin + (s + 2) * kBK, nxt2);                     // (past the end: clamped re-loads, never consumed)
+        const int nvalid = r_end - (r_begin + s * kBK);
+        if (nvalid < kBK) {                                      // the ragged last stage: surplus G rows contribute nothing
+            for (int id = tid; id < kBK * 32; id += 512) {
+                const int r = id >> 5;
+                if (r >= nvalid) *reinterpret_cast<uint4*>(cur + r * kTT + (id & 31) * 8) = make_uint4(0, 0, 0, 0);
+            }
+            lds_barrier();
+        }
+        compute(cur);
+        wait_barrier<NV>();                                      // stage s+1 has landed; stage s+2's copies stay in flight
+    };
+    copy(r_begin, smem);
+    copy(r_begin + kBK, smem + 2 * kStage);
+    wait_barrier<NV>();                                          // stage 0 landed
+    for (int s = 0; s < ns; s += 3) {
+        stage(s, smem, smem + 4 * kStage);
+        if (s + 1 < ns) stage(s + 1, smem + 2 * kStage, smem);
+        if (s + 2 < ns) stage(s + 2, smem + 4 * kStage, smem + 2 * kStage);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
+
+    if (!wave_on) return;
+    float* o = out + (int64_t)split * split_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = tk0 + wc * 128 + j * 32 + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tm0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < M) o[(int64_t)m * ld_out + k] = acc[i][j][r];
+            }
+    }
+}
+
 // dW = sum over splits of the partial panels (float64 accumulation); 4 splits x 4 elements in flight per thread
 __global__ __launch_bounds__(256) void reduce_splits_b16_kernel(const float* __restrict__ part, int64_t split_stride,
                                                                 int n_splits, float* __restrict__ dW, int64_t lddw, int M,
@@ -634,9 +760,17 @@ extern "C" int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t*
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
     dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(512);
+    static int tn_dma = -1;                                      // DDMP_TN_DMA=0: the register-staged kernel for every wgrad (A/B)
+    if (tn_dma < 0) {
+        const char* e = getenv("DDMP_TN_DMA");
+        tn_dma = (e && atoi(e) == 0) ? 0 : 1;
+    }
     if (pro_scale)
         hipLaunchKernelGGL((gemm_tn_b16_kernel<true>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
                            (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);
+    else if (tn_dma)
+        hipLaunchKernelGGL(gemm_tn_b16_dma_kernel, grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride, (int)n_rows, M,
+                           K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits);
     else
         hipLaunchKernelGGL((gemm_tn_b16_kernel<false>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
                            (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);
