@@ -518,20 +518,23 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_dma_kernel(
     const int piece = lane & 31;
     int64_t goff[2], zoff[2];
     int crow[2];
+    bool gon[2], zon[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = 2 * (8 * i + wave) + (lane >> 5);
         const int col = ((((piece >> 2) ^ (r & 3)) << 2) | (piece & 3)) * 8;      // logical column of this lane's piece
         crow[i] = r;
-        goff[i] = min(tm0 + col, M - 8);
+        gon[i] = tm0 + col < M;                                  // narrow operands: lanes beyond the width copy nothing.  Every
+        zon[i] = tk0 + col < K;                                  // instruction keeps lanes that do (columns 0..7 of its two rows),
+        goff[i] = min(tm0 + col, M - 8);                         // so each wave still issues exactly four copies per stage
         zoff[i] = min(tk0 + col, K - 8);
     }
     auto copy = [&](int r0, __bf16* buf) {                       // stage rows r0 .. r0 + 31 -> buf (G image, then Z image)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t row = min(r0 + crow[i], r_end - 1);
-            dma16(G + row * ldg + goff[i], buf + (8 * i + wave) * 512);
-            dma16(Z + row * ldz + zoff[i], buf + kStage + (8 * i + wave) * 512);
+            if (gon[i]) dma16(G + row * ldg + goff[i], buf + (8 * i + wave) * 512);
+            if (zon[i]) dma16(Z + row * ldz + zoff[i], buf + kStage + (8 * i + wave) * 512);
         }
     };
 
