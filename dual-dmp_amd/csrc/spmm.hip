@@ -492,193 +492,6 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 
 #include "fpartials.inc"
 
-// ------------------------------------------------------------------------------------------------
-//  Patch kernel with DMA staging (experiment, DDMP_SPMM_PATCH=1).  The slab kernel pays one L1 line lookup per
-//  gathered row and slab even when it hits (scripts/spmm_probe.py: +65 us per extra CSR entry per row at 1M x 512);
-//  a 64-row chunk of a Morton-ordered mesh references only ~100-120 distinct rows (1.6-1.9 per output row instead of
-//  4-7).  Per slab of 32 channels those rows ("patch", precomputed per chunk at graph build) are copied global -> LDS
-//  once by a fifth wave with global_load_lds_dwordx4 (8 rows x 128 B per instruction, no VGPRs), double buffered
-//  against the four compute waves, which gather from LDS by the entries' patch-local indices.  The DMA wave issues
-//  no stores, so its vmcnt(0) before the per-slab barrier waits for the copy only; the compute waves wait on
-//  lgkmcnt only and keep their Y stores in flight.
-//  Result: SLOWER (3.1 vs 4.4 TB/s on the Morton-ordered face graph).  52 KB of LDS allow 3 workgroups per CU and each
-//  has one slab (13 KB) in flight behind a per-slab barrier: ~40 KB in flight per CU against the slab kernel's 32
-//  waves x 4 KB, i.e. the copy latency is exposed.  A 32-row-chunk version (28 KB of LDS, 5 workgroups per CU) came to
-//  975 us (the slab kernel: 872 us on the same Morton-ordered face graph, 59 % of 8 TB/s), the vertex graph 697 vs 635 us:
-//  the per-slab barrier chain stays latency-bound.  Kept for A/B only.
-// ------------------------------------------------------------------------------------------------
-constexpr int kPMax = 176;          // patch rows (multiple of 8); Morton-ordered meshes: mean 100-120, max ~170
-
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void dma_barrier() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <bool PRO, bool RED>
-__global__ __launch_bounds__(320) void spmm_patch_dma_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-    const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
-    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
-    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int chunks_per_xcd, int n_chunks, BnRed red) {
-    constexpr int LANES = 8, CS = 32, U = 4;
-    __shared__ int s_rowptr[kRB + 1];
-    __shared__ unsigned short s_lc[kMaxE];
-    __shared__ float s_w[kMaxE];
-    __shared__ int s_pl[kPMax];
-    __shared__ __attribute__((aligned(16))) float patch[2][kPMax * CS];
-
-    const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
-    if (chunk >= n_chunks) return;
-    const int r0 = chunk * kRB;
-    const int nr = min(kRB, n_rows - r0);
-    const int tid = threadIdx.x;
-    for (int i = tid; i <= nr; i += 320) s_rowptr[i] = rowptr[r0 + i];
-    const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
-    for (int i = tid; i < np; i += 320) s_pl[i] = pl_col[p0 + i];
-    __syncthreads();
-    const int e0 = s_rowptr[0];
-    const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (dispatcher: max_row_nnz <= 16)
-    for (int t = tid; t < ne; t += 320) {
-        s_lc[t] = lcol[e0 + t];
-        s_w[t] = dinv[col[e0 + t]];
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = lane / LANES, sl = lane % LANES;
-    const int n_slabs = C / CS;
-    auto dma = [&](int slab, int buf) {                          // wave 4: patch rows of one slab, 8 rows per instruction
-        for (int j0 = 0; j0 < np; j0 += 8) {
-            const int row = s_pl[min(j0 + grp, np - 1)];
-            __builtin_amdgcn_global_load_lds(X + (int64_t)row * ldx + slab * CS + sl * 4, &patch[buf][j0 * CS], 16, 0, 0);
-        }
-    };
-    if (wave == 4) {
-        dma(0, 0);
-        dma_barrier();
-    } else {
-        lds_barrier();
-    }
-    for (int s = 0; s < n_slabs; ++s) {
-        const int buf = s & 1;
-        if (wave == 4) {
-            if (s + 1 < n_slabs) dma(s + 1, buf ^ 1);
-            dma_barrier();
-            continue;
-        }
-        const int off = s * CS + sl * 4;
-        float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO) {
-            pa = *reinterpret_cast<const float4*>(pscale + off);
-            pb = *reinterpret_cast<const float4*>(pshift + off);
-        }
-        const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 ra, rb, rmu, rrs, q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (RED) {
-            ra = *reinterpret_cast<const float4*>(red.scale + off);
-            rb = *reinterpret_cast<const float4*>(red.shift + off);
-            rmu = *reinterpret_cast<const float4*>(red.mean + off);
-            rrs = *reinterpret_cast<const float4*>(red.rstd + off);
-        }
-        const float* pt = &patch[buf][sl * 4];
-        for (int lr = wave * 8 + grp; lr < nr; lr += 32) {
-            const int es = s_rowptr[lr] - e0, ee = s_rowptr[lr + 1] - e0;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = es; e < ee; e += U) {
-                int li[U];
-                float wj[U];
-                float4 v[U];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int ek = min(e + k, ee - 1);
-                    li[k] = s_lc[ek];
-                    wj[k] = (e + k < ee) ? s_w[ek] : 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) v[k] = *reinterpret_cast<const float4*>(pt + li[k] * CS);
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    float4 t = v[k];
-                    if (PRO) t = f4_affine_lrelu(t, pa, pb, slope);
-                    acc.x = fmaf(wj[k], t.x, acc.x);
-                    acc.y = fmaf(wj[k], t.y, acc.y);
-                    acc.z = fmaf(wj[k], t.z, acc.z);
-                    acc.w = fmaf(wj[k], t.w, acc.w);
-                }
-            }
-            const int row = r0 + lr;
-            const float di = dinv[row];
-            float4 o;
-            o.x = fmaf(acc.x, di, bs.x);
-            o.y = fmaf(acc.y, di, bs.y);
-            o.z = fmaf(acc.z, di, bs.z);
-            o.w = fmaf(acc.w, di, bs.w);
-            nt_store4(Y + (int64_t)row * ldy + off, o);
-            if (RED) {
-                const float4 y = *reinterpret_cast<const float4*>(red.Yp + (int64_t)row * red.ldyp + off);
-                const float g0 = o.x * lrelu_grad(fmaf(y.x, ra.x, rb.x), slope);
-                const float g1 = o.y * lrelu_grad(fmaf(y.y, ra.y, rb.y), slope);
-                const float g2 = o.z * lrelu_grad(fmaf(y.z, ra.z, rb.z), slope);
-                const float g3 = o.w * lrelu_grad(fmaf(y.w, ra.w, rb.w), slope);
-                q0.x += g0; q0.y += g1; q0.z += g2; q0.w += g3;
-                q1.x = fmaf(g0, (y.x - rmu.x) * rrs.x, q1.x);
-                q1.y = fmaf(g1, (y.y - rmu.y) * rrs.y, q1.y);
-                q1.z = fmaf(g2, (y.z - rmu.z) * rrs.z, q1.z);
-                q1.w = fmaf(g3, (y.w - rmu.w) * rrs.w, q1.w);
-            }
-        }
-        if (RED) {
-            float v8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int o = LANES; o < 64; o <<= 1) v8[e] += __shfl_xor(v8[e], o, 64);
-            if (grp == 0) {
-                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
-                *reinterpret_cast<float4*>(pp) = make_float4(v8[0], v8[1], v8[2], v8[3]);
-                *reinterpret_cast<float4*>(pp + C) = make_float4(v8[4], v8[5], v8[6], v8[7]);
-            }
-        }
-        lds_barrier();
-    }
-}
-
-static bool patch_enabled() {                        // DDMP_SPMM_PATCH=1 selects it (A/B); off by default: measured
-    static int e = -1;                               // 1337 us vs 927 us for the slab kernel (face graph, 1M x 512)
-    if (e < 0) {
-        const char* v = getenv("DDMP_SPMM_PATCH");
-        e = (v && atoi(v) == 1) ? 1 : 0;
-    }
-    return e == 1;
-}
-static bool patch_ok(const ddmp_graph* g, int C) {
-    return patch_enabled() && g->max_patch > 0 && g->max_patch <= kPMax && g->max_row_nnz <= kMaxE / kRB && C % 32 == 0 && C >= 64;
-}
-template <bool RED>
-int launch_patch_dma(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
-                     const float* ps, const float* psh, float slope, hipStream_t st, BnRed red = BnRed()) {
-    const int n = (int)g->n_rows;
-    const int n_chunks = (int)cdiv(n, kRB);
-    const int cpx = (int)cdiv(n_chunks, kXcd);
-    dim3 grid(cpx * kXcd), block(320);
-    if (ps)
-        hipLaunchKernelGGL((spmm_patch_dma_kernel<true, RED>), grid, block, 0, st, g->rowptr, g->col, g->lcol, g->dinv,
-                           g->pl_ptr, g->pl_col, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
-    else
-        hipLaunchKernelGGL((spmm_patch_dma_kernel<false, RED>), grid, block, 0, st, g->rowptr, g->col, g->lcol, g->dinv,
-                           g->pl_ptr, g->pl_col, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
-    LAUNCH_TRY();
-    return DDMP_OK;
-}
-
 template <int LANES, int U, int NR, int SL = 1>
 int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
                 const float* ps, const float* psh, float slope, hipStream_t st) {
@@ -737,8 +550,6 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
                                         nullptr, nullptr, nullptr, nullptr, st);
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
-    if (vec && spmm_mode >= 4 && patch_ok(g, C))
-        return launch_patch_dma<false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
     if (vec && spmm_mode >= 4 && C >= 32 && C % 32 == 0) {
         // 4 gathers in flight per lane measured best (8 in flight -- one batch of 8, or two rows x 4 -- was 3-5 %
         // slower: the kernel is bound by on-chip issue / L1 cost per gathered row, not by memory latency);
@@ -831,14 +642,6 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
             return DDMP_OK;
         }
         if (rc != ddmp::kPatchNotApplicable) return rc;
-    }
-    if (patch_ok(g, C)) {
-        int rc = launch_patch_dma<true>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
-        if (rc != DDMP_OK) return rc;
-        const size_t pbytes2 = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-        fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes2), sums2, st);
-        LAUNCH_TRY();
-        return DDMP_OK;
     }
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
                        g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,

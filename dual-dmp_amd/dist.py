@@ -471,7 +471,11 @@ class DistributedTrainer:
         self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
                               comm=GraphComm(backend, sd.fplan, device), n_total=sd.F,
                               dtype=getattr(normnet, "feature_dtype", torch.float32))
-        posnet._engine, normnet._engine = self.peng, self.neng
+        for net, eng in ((posnet, self.peng), (normnet, self.neng)):
+            if hasattr(net, "attach_engine"):
+                net.attach_engine(eng)                          # net(data) then runs on this rank's shard
+            else:
+                net._engine = eng
         self.owned_v = torch.from_numpy(sd.vplan.owned).to(device)
         self.owned_f = torch.from_numpy(sd.fplan.owned).to(device)
         self.full = torch.zeros((sd.V + sd.F + 1, 3), dtype=torch.float32, device=device)     # + the scratch row of the pads

@@ -267,8 +267,8 @@ class GcnEngine:
             if h is not None:
                 h.wait()
 
-    def forward(self, params: torch.Tensor, update_running: bool = True) -> torch.Tensor:
-        self._drain(self.forward_steps(params, update_running))
+    def forward(self, params: torch.Tensor, update_running: bool = True, use_running: bool = False) -> torch.Tensor:
+        self._drain(self.forward_steps(params, update_running, use_running))
         return self.result
 
     def backward(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
@@ -276,7 +276,17 @@ class GcnEngine:
         self._drain(self.backward_steps(params, grads, dout))
         return grads
 
-    def forward_steps(self, params: torch.Tensor, update_running: bool = True):
+    def _bn4_from_running(self, l, gamma, beta):
+        """eval() mode of nn.BatchNorm1d: normalise with the running statistics (a handful of C-length torch ops)."""
+        rm, rv = self.running[l][0], self.running[l][1]
+        rstd = torch.rsqrt(rv + ops.BN_EPS)
+        b = self.bn4[l]
+        b[0] = gamma * rstd
+        b[1] = beta - rm * b[0]
+        b[2] = rm
+        b[3] = rstd
+
+    def forward_steps(self, params: torch.Tensor, update_running: bool = True, use_running: bool = False):
         """The forward pass as a generator that yields at every collective it STARTS (halo exchange, BatchNorm
         statistics all-reduce): the caller waits on the handle before resuming.  A multi-device trainer runs the
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
@@ -320,8 +330,11 @@ class GcnEngine:
                 h_stats = comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
                 h_halo = comm.start_halo(Y, n) if halo_started else None
                 yield _Both(h_stats, h_halo)
-            ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
-                           self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
+            if use_running:
+                self._bn4_from_running(l, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i))
+            else:
+                ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
+                               self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
             X, pro = Y, (self.bn4[l][0], self.bn4[l][1])
         if update_running:
             self.num_batches_tracked += 1

@@ -38,14 +38,19 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, arena, net):
         eng = net._engine
         with ops.on_device(eng.device):
-            out = eng.forward(arena.detach(), update_running=net.training)
+            # nn.BatchNorm1d semantics: batch statistics (+ running-stat update) in train mode, running statistics in eval mode
+            out = eng.forward(arena.detach(), update_running=net.training, use_running=not net.training)
             ctx.net = net
+            ctx.trained = net.training
             return out.clone()
 
     @staticmethod
     def backward(ctx, dout):
         net = ctx.net
         eng = net._engine
+        if not ctx.trained:
+            raise RuntimeError("backward through a fused net in eval() mode is not implemented (the reference never leaves "
+                               "train mode, main.py:88-89): call net.train() before the forward pass")
         with ops.on_device(eng.device):
             eng.backward(net.arena.detach(), net._grad_arena, dout)
             if eng.comm.world_size > 1:
@@ -84,34 +89,80 @@ class _FusedNet(nn.Module):
     def num_parameters(self):
         return self.layout.n_true_params()
 
+    def _buffers_now(self):
+        """BatchNorm buffers under the reference's names: the live engine's, else what a load left pending, else the
+        nn.BatchNorm1d defaults (mean 0, var 1, 0 batches)."""
+        eng, pend = self._engine, getattr(self, "_pending_running", None) or {}
+        out = OrderedDict()
+        for l in range(12):
+            c = self.layout.cout[l]
+            for j, nm in enumerate(("running_mean", "running_var")):
+                k = "bn%d.%s" % (l + 1, nm)
+                if eng is not None:
+                    out[k] = eng.running[l][j].clone()
+                elif k in pend:
+                    out[k] = pend[k].clone()
+                else:
+                    out[k] = torch.full((c,), float(j), dtype=torch.float32, device=self.device)
+            k = "bn%d.num_batches_tracked" % (l + 1)
+            out[k] = (eng.num_batches_tracked[l].clone() if eng is not None else
+                      pend[k].clone() if k in pend else torch.zeros((), dtype=torch.int64, device=self.device))
+        return out
+
     def state_dict(self, *args, **kwargs):
         sd = OrderedDict()
         for name, v in self.named_views().items():
             sd[name] = v.detach().clone()
-        eng = self._engine
-        for l in range(12):
-            if eng is not None:
-                sd["bn%d.running_mean" % (l + 1)] = eng.running[l][0].clone()
-                sd["bn%d.running_var" % (l + 1)] = eng.running[l][1].clone()
-                sd["bn%d.num_batches_tracked" % (l + 1)] = eng.num_batches_tracked[l].clone()
+        sd.update(self._buffers_now())
         return sd
 
     def load_state_dict(self, sd, strict=True):
+        """Reference-named keys (``conv1.lin.weight`` ... ``linear2.bias``, ``bnN.running_mean/var/num_batches_tracked``);
+        returns the (missing_keys, unexpected_keys) pair like ``nn.Module.load_state_dict``.  BatchNorm buffers go into the
+        live engine at once (or wait for the engine to be built)."""
+        from torch.nn.modules.module import _IncompatibleKeys
         views = self.named_views()
+        buf_keys = set(self._buffers_now().keys())
+        missing = [k for k in list(views) + sorted(buf_keys) if k not in sd]
+        unexpected = [k for k in sd if k not in views and k not in buf_keys]
+        if strict and (missing or unexpected):
+            raise KeyError("load_state_dict: missing keys %s, unexpected keys %s" % (missing, unexpected))
         with torch.no_grad():
             for name, v in views.items():
                 if name in sd:
                     v.copy_(sd[name].to(v.device, torch.float32))
-                elif strict:
-                    raise KeyError("missing key %s" % name)
-        self._pending_running = {k: v.detach().clone() for k, v in sd.items() if "running_" in k}
-        return self
+            self._pending_running = {k: sd[k].detach().clone() for k in buf_keys if k in sd}
+            self._apply_pending_running()
+        return _IncompatibleKeys(missing, unexpected)
+
+    def _apply_pending_running(self):
+        eng, pend = self._engine, getattr(self, "_pending_running", None)
+        if eng is None or not pend:
+            return
+        for l in range(12):
+            for j, nm in enumerate(("running_mean", "running_var")):
+                k = "bn%d.%s" % (l + 1, nm)
+                if k in pend:
+                    eng.running[l][j].copy_(pend[k].to(eng.device, torch.float32))
+            k = "bn%d.num_batches_tracked" % (l + 1)
+            if k in pend:
+                eng.num_batches_tracked[l] = int(pend[k])
+        self._pending_running = None
 
     # ------------------------------------------------------------ engine plumbing
     def _inputs(self, data):
         raise NotImplementedError
 
+    def attach_engine(self, engine):
+        """Install an engine built elsewhere (dist.DistributedTrainer: this rank's shard of the graph); ``net(data)`` then
+        runs on it instead of building a single-device engine for ``data``."""
+        self._engine = engine
+        self._engine_key = "external"
+        self._apply_pending_running()
+
     def _get_engine(self, data):
+        if self._engine is not None and self._engine_key == "external":
+            return self._engine
         x0, x_pos, edge_index = self._inputs(data)
         key = self._engine_key
         same = (self._engine is not None and key is not None and key[0]() is x0 and key[1]() is edge_index
@@ -134,13 +185,7 @@ class _FusedNet(nn.Module):
             self._engine = GcnEngine(graph, self._widths, self._kind, x0d, xpd, comm=self.comm, perm=perm,
                                      dtype=self.feature_dtype)
             self._engine_key = (weakref.ref(x0), weakref.ref(edge_index), (x0._version, edge_index._version))
-            pend = getattr(self, "_pending_running", None)
-            if pend:
-                for l in range(12):
-                    for j, nm in enumerate(("running_mean", "running_var")):
-                        k = "bn%d.%s" % (l + 1, nm)
-                        if k in pend:
-                            self._engine.running[l][j].copy_(pend[k].to(dev))
+            self._apply_pending_running()
         return self._engine
 
     def _coords(self, x0, x_pos):

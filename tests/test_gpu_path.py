@@ -191,6 +191,42 @@ def test_nets_forward_backward_match_oracle(dev, oracle, fused, which):
         assert int(sd["bn3.num_batches_tracked"]) == 1
 
 
+def test_fused_net_follows_nn_module_semantics(dev, oracle):
+    """eval() normalises with the running statistics like nn.BatchNorm1d, state_dict() always carries the BatchNorm buffers,
+    load_state_dict() reaches a live engine and reports missing / unexpected keys."""
+    from dual_dmp_amd.networks import PosNet
+    gt, noisy, smooth, data = _case(dev, "ico3")
+    odata = oracle.OracleDataset(noisy, smooth)
+    torch.manual_seed(3)
+    ref = oracle.PosNetRef()
+    net = PosNet(dev)
+    sd0 = net.state_dict()
+    assert "bn7.running_var" in sd0 and float(sd0["bn7.running_var"].mean()) == 1.0      # before any engine exists
+    res = net.load_state_dict(ref.state_dict())
+    assert list(res.missing_keys) == [] and list(res.unexpected_keys) == []
+    ref.train(); net.train()
+    for _ in range(2):                                           # two training forwards move the running statistics
+        ref(odata); net(data)
+    sd = net.state_dict()
+    assert relerr(sd["bn12.running_mean"], ref.bn12.running_mean) < 1e-4
+    assert int(sd["bn3.num_batches_tracked"]) == 2
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        assert float((net(data).cpu() - ref(odata)).abs().max()) < 2e-4
+    # a second net picks the buffers up from the state dict, also when its engine already exists
+    net2 = PosNet(dev)
+    net2.train()
+    net2(data)
+    net2.load_state_dict(sd)
+    net2.eval()
+    with torch.no_grad():
+        assert float((net2(data) - net(data)).abs().max()) < 1e-6
+    with pytest.raises(KeyError):
+        net2.load_state_dict({"bogus": torch.zeros(1)})
+    bad = net2.load_state_dict({"bogus": torch.zeros(1)}, strict=False)
+    assert "bogus" in bad.unexpected_keys and "conv1.lin.weight" in bad.missing_keys
+
+
 def _oracle_nets(oracle, sd_pos, sd_norm, dtype=torch.float32):
     posnet, normnet = oracle.PosNetRef(), oracle.NormalNetRef()
     posnet.load_state_dict(sd_pos)
