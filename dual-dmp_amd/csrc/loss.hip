@@ -52,21 +52,23 @@ __global__ __launch_bounds__(256) void vertex_fwd_kernel(int V, const float* __r
                                                          const double* __restrict__ real,
                                                          const int* __restrict__ vv_ptr,
                                                          const int* __restrict__ vv_idx, float* __restrict__ resid,
-                                                         double* __restrict__ partials) {
+                                                         double* __restrict__ partials,
+                                                         const unsigned char* __restrict__ own /* nullable: sums over own[v] != 0 */) {
     __shared__ double sm[4];
     double s1 = 0.0, s2 = 0.0;
     for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += kNB * 256) {
+        const double m = (own && !own[v]) ? 0.0 : 1.0;           // ghost rows of a shard are computed, not counted
         const F3 p = ld3(pos, v);
         const double dx = real[3 * (int64_t)v] - (double)p.x, dy = real[3 * (int64_t)v + 1] - (double)p.y,
                      dz = real[3 * (int64_t)v + 2] - (double)p.z;
-        s1 += dx * dx + dy * dy + dz * dz;
+        s1 += m * (dx * dx + dy * dy + dz * dz);
         F3 acc = {0.f, 0.f, 0.f};
         const int b = vv_ptr[v], e = vv_ptr[v + 1];
         for (int k = b; k < e; ++k) acc = acc + ld3(pos, vv_idx[k]);
         const float deg = (float)(e - b);
         const F3 r = {p.x - acc.x / deg, p.y - acc.y / deg, p.z - acc.z / deg};
         st3(resid, v, r);
-        s2 += (double)(r.x * r.x + r.y * r.y + r.z * r.z);
+        s2 += m * (double)(r.x * r.x + r.y * r.y + r.z * r.z);
     }
     put_partial(s1, partials, P_S1, sm);
     put_partial(s2, partials, P_S2, sm);
@@ -77,10 +79,12 @@ __global__ __launch_bounds__(256) void face_fwd_kernel(int F, const float* __res
                                                        const double* __restrict__ real_n,
                                                        const int* __restrict__ faces, float* __restrict__ fc,
                                                        float* __restrict__ fa, float* __restrict__ pn_coef,
-                                                       float* __restrict__ pn_dn, double* __restrict__ partials) {
+                                                       float* __restrict__ pn_dn, double* __restrict__ partials,
+                                                       const unsigned char* __restrict__ own) {
     __shared__ double sm[4];
     double s3 = 0.0, s5 = 0.0;
     for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += kNB * 256) {
+        const double m = (own && !own[f]) ? 0.0 : 1.0;
         const int i0 = faces[3 * (int64_t)f], i1 = faces[3 * (int64_t)f + 1], i2 = faces[3 * (int64_t)f + 2];
         const F3 p0 = ld3(pos, i0), p1 = ld3(pos, i1), p2 = ld3(pos, i2);
         const F3 c = {(p0.x + p1.x + p2.x) / 3.0f, (p0.y + p1.y + p2.y) / 3.0f, (p0.z + p1.z + p2.z) / 3.0f};
@@ -89,11 +93,11 @@ __global__ __launch_bounds__(256) void face_fwd_kernel(int F, const float* __res
         st3(fc, f, c);
         fa[f] = 0.5f * sqrtf(dot(cr, cr) + 1.0e-12f);
         const F3 n = ld3(nrm, f);
-        s3 += fabs((double)n.x - real_n[3 * (int64_t)f]) + fabs((double)n.y - real_n[3 * (int64_t)f + 1]) +
-              fabs((double)n.z - real_n[3 * (int64_t)f + 2]);
+        s3 += m * (fabs((double)n.x - real_n[3 * (int64_t)f]) + fabs((double)n.y - real_n[3 * (int64_t)f + 1]) +
+                   fabs((double)n.z - real_n[3 * (int64_t)f + 2]));
         const F3 q0 = p0 - c, q1 = p1 - c, q2 = p2 - c;
         const float d0 = dot(q0, n), d1 = dot(q1, n), d2 = dot(q2, n);
-        s5 += (double)(fabsf(d0) + fabsf(d1) + fabsf(d2));
+        s5 += m * (double)(fabsf(d0) + fabsf(d1) + fabsf(d2));
         const float g0 = sgn(d0), g1 = sgn(d1), g2 = sgn(d2);
         const float gs = (g0 + g1 + g2) / 3.0f;
         st3(pn_coef, f, F3{g0 - gs, g1 - gs, g2 - gs});
@@ -105,10 +109,12 @@ __global__ __launch_bounds__(256) void face_fwd_kernel(int F, const float* __res
 
 __global__ __launch_bounds__(256) void bnf_sigma_kernel(int F, const float* __restrict__ fc,
                                                         const int* __restrict__ f2f, float* __restrict__ fcd,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials,
+                                                        const unsigned char* __restrict__ own) {
     __shared__ double sm[4];
     double s = 0.0;
     for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += kNB * 256) {
+        const double m = (own && !own[f]) ? 0.0 : 1.0;
         const F3 c = ld3(fc, f);
         float d[3];
 #pragma unroll
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256) void bnf_sigma_kernel(int F, const float* __re
             if (j < 0) j = F - 1;                       // python negative index: the last face
             const F3 t = ld3(fc, j) - c;
             d[k] = dot(t, t);
-            s += (double)sqrtf(d[k] + 1.0e-12f);
+            s += m * (double)sqrtf(d[k] + 1.0e-12f);
         }
         st3(fcd, f, F3{d[0], d[1], d[2]});
     }
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(256) void bnf_iter_kernel(int F, const float* __res
                                                        const int* __restrict__ f2f,
                                                        const float* __restrict__ fcd, const float* __restrict__ fa,
                                                        const double* __restrict__ partials,
-                                                       float* __restrict__ Aout, float* __restrict__ next) {
-    const float i2sc = sigma_c_inv2(partials, F);
+                                                       float* __restrict__ Aout, float* __restrict__ next, int F_glob) {
+    const float i2sc = sigma_c_inv2(partials, F_glob);           // sigma_c is a mean over ALL faces of the mesh
     const float i2ss = 1.0f / (2.0f * kSigmaS2);
     for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += gridDim.x * 256) {
         const F3 nf = ld3(cur, f);
@@ -159,11 +165,12 @@ __global__ __launch_bounds__(256) void bnf_iter_kernel(int F, const float* __res
 
 __global__ __launch_bounds__(256) void bnf_diff_kernel(int F, const float* __restrict__ n_last,
                                                        const float* __restrict__ n0,
-                                                       double* __restrict__ partials) {
+                                                       double* __restrict__ partials,
+                                                       const unsigned char* __restrict__ own) {
     __shared__ double sm[4];
     double s = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 3 * (int64_t)F; i += kNB * 256)
-        s += (double)fabsf(n_last[i] - n0[i]);
+        if (!own || own[i / 3]) s += (double)fabsf(n_last[i] - n0[i]);
     put_partial(s, partials, P_S4, sm);
 }
 
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(256) void bnf_bwd_gather_kernel(int F, const float*
                                                              const float* __restrict__ fcd,
                                                              const float* __restrict__ fa,
                                                              const double* __restrict__ partials,
-                                                             float* __restrict__ Gout) {
-    const float i2sc = sigma_c_inv2(partials, F);
+                                                             float* __restrict__ Gout, int F_glob) {
+    const float i2sc = sigma_c_inv2(partials, F_glob);
     const float i2ss = 1.0f / (2.0f * kSigmaS2);
     const float iss = 1.0f / kSigmaS2;
     for (int j = blockIdx.x * 256 + threadIdx.x; j < F; j += gridDim.x * 256) {
@@ -307,46 +314,73 @@ int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdi
 
 extern "C" size_t ddmp_loss_partials_bytes(void) { return sizeof(double) * P_COUNT * kNB; }
 
+extern "C" int ddmp_loss_vertex_fwd_part(int64_t V, const float* pos, const double* real_pos, const int32_t* vv_ptr,
+                                         const int32_t* vv_idx, float* resid, double* partials,
+                                         const uint8_t* own, ddmp_stream stream) {
+    ARG_TRY(V > 0 && V < INT32_MAX && pos && real_pos && vv_ptr && vv_idx && resid && partials);
+    hipLaunchKernelGGL(vertex_fwd_kernel, dim3(kNB), dim3(256), 0, (hipStream_t)stream, (int)V, pos, real_pos,
+                       vv_ptr, vv_idx, resid, partials, own);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
 extern "C" int ddmp_loss_vertex_fwd(int64_t V, const float* pos, const double* real_pos, const int32_t* vv_ptr,
                                     const int32_t* vv_idx, float* resid, double* partials,
                                     ddmp_stream stream) {
-    ARG_TRY(V > 0 && V < INT32_MAX && pos && real_pos && vv_ptr && vv_idx && resid && partials);
-    hipLaunchKernelGGL(vertex_fwd_kernel, dim3(kNB), dim3(256), 0, (hipStream_t)stream, (int)V, pos, real_pos,
-                       vv_ptr, vv_idx, resid, partials);
+    return ddmp_loss_vertex_fwd_part(V, pos, real_pos, vv_ptr, vv_idx, resid, partials, nullptr, stream);
+}
+
+extern "C" int ddmp_loss_face_fwd_part(int64_t F, const float* pos, const float* norm, const double* real_norm,
+                                       const int32_t* faces, float* fc, float* fa, float* pn_coef, float* pn_dn,
+                                       double* partials, const uint8_t* own, ddmp_stream stream) {
+    ARG_TRY(F > 0 && F < INT32_MAX / 3 && pos && norm && real_norm && faces && fc && fa && pn_coef && pn_dn && partials);
+    hipLaunchKernelGGL(face_fwd_kernel, dim3(kNB), dim3(256), 0, (hipStream_t)stream, (int)F, pos, norm, real_norm,
+                       faces, fc, fa, pn_coef, pn_dn, partials, own);
     LAUNCH_TRY();
     return DDMP_OK;
 }
-
 extern "C" int ddmp_loss_face_fwd(int64_t F, const float* pos, const float* norm, const double* real_norm,
                                   const int32_t* faces, float* fc, float* fa, float* pn_coef, float* pn_dn,
                                   double* partials, ddmp_stream stream) {
-    ARG_TRY(F > 0 && F < INT32_MAX / 3 && pos && norm && real_norm && faces && fc && fa && pn_coef && pn_dn && partials);
-    hipLaunchKernelGGL(face_fwd_kernel, dim3(kNB), dim3(256), 0, (hipStream_t)stream, (int)F, pos, norm, real_norm,
-                       faces, fc, fa, pn_coef, pn_dn, partials);
+    return ddmp_loss_face_fwd_part(F, pos, norm, real_norm, faces, fc, fa, pn_coef, pn_dn, partials, nullptr, stream);
+}
+
+// bnf_n: [(loop+1), F, 3] (slot 0 receives a copy of `norm`), bnf_A: [loop, F, 3], fcd: [F,3].
+// Two halves so that a sharded caller can all-reduce the sigma_c partial sums in between:
+//   ddmp_loss_bnf_sigma   copy of norm into slot 0, centroid distances fcd, partial sums of sigma_c (over own faces)
+//   ddmp_loss_bnf_filter  `loop` filter passes with sigma_c = sum(partials) / (3 F_glob), then the L1 partial sums
+extern "C" int ddmp_loss_bnf_sigma(int64_t F, const float* norm, const int32_t* f2f, const float* fc, float* fcd,
+                                   float* bnf_n, double* partials, const uint8_t* own, ddmp_stream stream) {
+    ARG_TRY(F > 0 && F < INT32_MAX / 3 && norm && f2f && fc && fcd && bnf_n && partials);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(bnf_n, norm, sizeof(float) * 3 * (size_t)F, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(bnf_sigma_kernel, dim3(kNB), dim3(256), 0, st, (int)F, fc, f2f, fcd, partials, own);
     LAUNCH_TRY();
     return DDMP_OK;
 }
-
-// bnf_n: [(loop+1), F, 3] (slot 0 receives a copy of `norm`), bnf_A: [loop, F, 3], fcd: [F,3]
+extern "C" int ddmp_loss_bnf_filter(int64_t F, int64_t F_glob, const int32_t* f2f, const float* fcd, const float* fa,
+                                    int loop, float* bnf_n, float* bnf_A, double* partials, const uint8_t* own,
+                                    ddmp_stream stream) {
+    ARG_TRY(F > 0 && F < INT32_MAX / 3 && F_glob > 0 && F_glob < INT32_MAX / 3 && f2f && fcd && fa && loop >= 0 && bnf_n && partials);
+    ARG_TRY(loop == 0 || bnf_A);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(F);
+    for (int t = 0; t < loop; ++t) {
+        hipLaunchKernelGGL(bnf_iter_kernel, dim3(grid), dim3(256), 0, st, (int)F, bnf_n + (size_t)t * 3 * F, f2f, fcd,
+                           fa, partials, bnf_A + (size_t)t * 3 * F, bnf_n + (size_t)(t + 1) * 3 * F, (int)F_glob);
+        LAUNCH_TRY();
+    }
+    hipLaunchKernelGGL(bnf_diff_kernel, dim3(kNB), dim3(256), 0, st, (int)F, bnf_n + (size_t)loop * 3 * F, bnf_n,
+                       partials, own);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
 extern "C" int ddmp_loss_bnf_fwd(int64_t F, const float* norm, const int32_t* f2f, const float* fc,
                                  const float* fa, int loop, float* fcd, float* bnf_n, float* bnf_A,
                                  double* partials, ddmp_stream stream) {
     ARG_TRY(F > 0 && F < INT32_MAX / 3 && norm && f2f && fc && fa && loop >= 0 && fcd && bnf_n && partials);
-    ARG_TRY(loop == 0 || bnf_A);
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(bnf_n, norm, sizeof(float) * 3 * (size_t)F, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(bnf_sigma_kernel, dim3(kNB), dim3(256), 0, st, (int)F, fc, f2f, fcd, partials);
-    LAUNCH_TRY();
-    const int grid = grid_for(F);
-    for (int t = 0; t < loop; ++t) {
-        hipLaunchKernelGGL(bnf_iter_kernel, dim3(grid), dim3(256), 0, st, (int)F, bnf_n + (size_t)t * 3 * F, f2f, fcd,
-                           fa, partials, bnf_A + (size_t)t * 3 * F, bnf_n + (size_t)(t + 1) * 3 * F);
-        LAUNCH_TRY();
-    }
-    hipLaunchKernelGGL(bnf_diff_kernel, dim3(kNB), dim3(256), 0, st, (int)F, bnf_n + (size_t)loop * 3 * F, bnf_n,
-                       partials);
-    LAUNCH_TRY();
-    return DDMP_OK;
+    int rc = ddmp_loss_bnf_sigma(F, norm, f2f, fc, fcd, bnf_n, partials, nullptr, stream);
+    if (rc != DDMP_OK) return rc;
+    return ddmp_loss_bnf_filter(F, F, f2f, fcd, fa, loop, bnf_n, bnf_A, partials, nullptr, stream);
 }
 
 extern "C" int ddmp_loss_finalize(const double* partials, int64_t V, int64_t F, const double* k5 /*host [5]*/,
@@ -363,7 +397,12 @@ extern "C" int ddmp_loss_finalize(const double* partials, int64_t V, int64_t F, 
 extern "C" int ddmp_loss_bnf_bwd(int64_t F, const int32_t* f2f, const float* fa, const float* fcd, int loop,
                                  const float* bnf_n, const float* bnf_A, const double* partials,
                                  const double* coef, float* G0, float* scratch, ddmp_stream stream) {
-    ARG_TRY(F > 0 && F < INT32_MAX / 3 && f2f && fa && fcd && loop >= 0 && bnf_n && partials && coef && G0);
+    return ddmp_loss_bnf_bwd_part(F, F, f2f, fa, fcd, loop, bnf_n, bnf_A, partials, coef, G0, scratch, stream);
+}
+extern "C" int ddmp_loss_bnf_bwd_part(int64_t F, int64_t F_glob, const int32_t* f2f, const float* fa, const float* fcd,
+                                      int loop, const float* bnf_n, const float* bnf_A, const double* partials,
+                                      const double* coef, float* G0, float* scratch, ddmp_stream stream) {
+    ARG_TRY(F > 0 && F < INT32_MAX / 3 && F_glob > 0 && f2f && fa && fcd && loop >= 0 && bnf_n && partials && coef && G0);
     ARG_TRY(loop == 0 || (bnf_A && scratch));
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(3 * F), gridf = grid_for(F);
@@ -377,7 +416,7 @@ extern "C" int ddmp_loss_bnf_bwd(int64_t F, const int32_t* f2f, const float* fa,
         hipLaunchKernelGGL(bnf_bwd_dA_kernel, dim3(gridf), dim3(256), 0, st, (int)F, Ga, bnf_A + (size_t)t * 3 * F, dA);
         LAUNCH_TRY();
         hipLaunchKernelGGL(bnf_bwd_gather_kernel, dim3(gridf), dim3(256), 0, st, (int)F, bnf_n + (size_t)t * 3 * F, dA,
-                           f2f, fcd, fa, partials, Gb);
+                           f2f, fcd, fa, partials, Gb, (int)F_glob);
         LAUNCH_TRY();
         std::swap(Ga, Gb);
     }

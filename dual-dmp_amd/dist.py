@@ -12,9 +12,13 @@ The reference is single-device; this is the build's own row (e
 * BatchNorm statistics: float64 column sums all-reduced (2*C values) before ``bn_prepare`` /
   ``bn_bwd_prepare``; weight gradients: one all-reduce of the flat gradient arena per net and step
   (BN weight/bias gradients are already global and are excluded from the sum).
-* The five losses are O(V+F) streaming work (<2 % of the step) full of global quirks (sigma_c over all
-  faces, -1 -> LAST face): they are REPLICATED: ``pos``/``norm`` of the owned rows are all-reduced into full
-  arrays, every rank runs the unchanged :class:`loss.LossEngine` and keeps the gradient rows it owns.
+* The five losses (<2 % of the step) are SHARDED by recomputation, not by exchange: a rank sums the loss terms of the
+  rows it owns and keeps their gradient rows, and evaluates everything those read on a ghost closure
+  (:class:`LossShard`: ``2*loop+1`` face rings for the bilateral filter, two vertex rings for the Laplacian, the faces
+  around owned vertices, and the mesh's LAST face -- what f2f == -1 gathers).  Per step: two ghost exchanges (vertex
+  positions, face normals: the same grouped send/recv as a layer's halo) and two all-reduces of float64 partial sums
+  (sigma_c, a mean over ALL faces, before the filter passes; S1..S5 before the loss scalars).  ``losses="replicated"``
+  keeps the round-1 form (all-gather pos | norm, every rank runs the whole-mesh :class:`loss.LossEngine`).
 * Parameters are replicated; identical reduced gradients + identical Adam state keep them bit-identical.
 
 Communicators: :class:`TorchDistComm` (nccl = RCCL on GPUs, gloo in the CPU tests) and :class:`ThreadComm`
@@ -399,7 +403,7 @@ def _shared_global_tables(dataset, n_mesh, P, face_owner):
     """The rank-independent part of the partition (owners, the two global CSRs, Morton keys), built ONCE per process and
     (dataset, P): logical ranks that live in one process (ThreadComm: tests, single-GPU emulation of an 8-way run) share
     it instead of each repeating O(global mesh) numpy work; one process per GPU builds it once anyway."""
-    key = (id(dataset), id(n_mesh), P)
+    key = (id(dataset), id(n_mesh), P, None if face_owner is None else hash(np.asarray(face_owner).tobytes()))
     with _global_lock:
         hit = _global_tables.get(key)
         if hit is not None and hit[0] is dataset:
@@ -435,6 +439,155 @@ def _shared_global_tables(dataset, n_mesh, P, face_owner):
         return tables
 
 
+# ------------------------------------------------------------------------------------ sharded losses
+def _csr_rows(ptr: np.ndarray, idx: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    """Concatenated CSR rows `rows` of (ptr, idx)."""
+    cnt = (ptr[rows + 1] - ptr[rows]).astype(np.int64)
+    if cnt.sum() == 0:
+        return np.empty(0, dtype=idx.dtype)
+    base = np.repeat(ptr[rows].astype(np.int64) - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
+    return idx[base + np.arange(int(cnt.sum()), dtype=np.int64)]
+
+
+class GhostPlan:
+    """Exchange schedule of a ghost closure, with the fields :class:`GraphComm` / :class:`NativeComm` read from a
+    :class:`HaloPlan` (owned rows first, then the ghost rows grouped by source rank and id)."""
+
+    def __init__(self, ext_by_rank, owner: np.ndarray, rank: int, P: int, owned: np.ndarray):
+        """``ext_by_rank[d]``: sorted global ids rank d needs (a superset of what it owns is fine); ``owned``: this rank's
+        owned ids in the row order of its engine."""
+        n = len(owner)
+        self.rank, self.P, self.owned = rank, P, owned
+        mine = ext_by_rank[rank]
+        ghost = mine[owner[mine] != rank]
+        self.halo = ghost[np.lexsort((ghost, owner[ghost]))]
+        self.recv_counts = np.bincount(owner[self.halo], minlength=P).astype(np.int64).tolist()
+        g2l = np.full(n, -1, dtype=np.int64)
+        g2l[owned] = np.arange(len(owned))
+        send, counts = [], []
+        for d in range(P):
+            ids = ext_by_rank[d] if d != rank else np.empty(0, dtype=np.int64)
+            ids = ids[owner[ids] == rank]                               # ascending ids = the receiver's order
+            send.append(g2l[ids])
+            counts.append(len(ids))
+        self.send_idx = np.concatenate(send).astype(np.int64) if send else np.empty(0, dtype=np.int64)
+        assert (self.send_idx >= 0).all()
+        self.send_counts = counts
+        self.n_rows, self.n_cols = len(owned), len(owned) + len(self.halo)
+        self.local_ids = np.concatenate([owned, self.halo])
+        self.n_global = n
+
+
+def _loss_closures(n_mesh, face_owner, vert_owner, P, loop):
+    """For every rank: the faces and vertices its share of the losses (util/loss.py:16-160) reads.
+
+    Owned rows = the rows whose loss terms the rank SUMS and whose gradient rows it keeps.  A loss term's gradient reaches
+    rows of other ranks and, for the bilateral filter (fn_bnf_loss, util/loss.py:86-137), other ranks' terms reach owned
+    rows; instead of exchanging inside the losses a rank recomputes what it needs on a ghost closure:
+
+    * faces: ``2*loop + 1`` rings (f2f) around the owned faces -- the filtered normal n^t is exact where its ring is
+      present, loss terms within ``loop`` rings send gradient to an owned normal, and their backward reads one more ring
+      -- plus every face incident to an owned vertex (pos_norm_loss gradient, util/loss.py:140-160) and the mesh's LAST
+      face (what f2f == -1 gathers in the reference: ``fn[f2f]`` with index -1);
+    * vertices: the corners of those faces and two rings around the owned vertices (the Laplacian residual of a
+      neighbour reads that neighbour's neighbours, util/loss.py:37-52).
+    """
+    faces = np.ascontiguousarray(n_mesh.faces, dtype=np.int64)
+    f2f = np.ascontiguousarray(n_mesh.f2f, dtype=np.int64)
+    V, F = len(n_mesh.vs), len(faces)
+    e = np.asarray(n_mesh.edges, dtype=np.int64)
+    src, dst = np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]])
+    o = np.argsort(src, kind="stable")
+    vv_ptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=V), out=vv_ptr[1:])
+    vv_idx = dst[o]
+    flat = faces.reshape(-1)
+    vf_ptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(np.bincount(flat, minlength=V), out=vf_ptr[1:])
+    vf_idx = np.argsort(flat, kind="stable") // 3
+    rings = 2 * int(loop) + 1
+    fext, vext = [], []
+    for r in range(P):
+        fo, vo = np.flatnonzero(face_owner == r), np.flatnonzero(vert_owner == r)
+        fin = np.zeros(F, dtype=bool)
+        fin[fo] = True
+        front = fo
+        for _ in range(rings):
+            nb = f2f[front].reshape(-1)
+            nb = nb[nb >= 0]
+            nb = np.unique(nb[~fin[nb]])
+            if nb.size == 0:
+                break
+            fin[nb] = True
+            front = nb
+        fin[_csr_rows(vf_ptr, vf_idx, vo)] = True
+        fin[F - 1] = True
+        vin = np.zeros(V, dtype=bool)
+        vin[vo] = True
+        front = vo
+        for _ in range(2):
+            nb = _csr_rows(vv_ptr, vv_idx, front)
+            nb = np.unique(nb[~vin[nb]])
+            if nb.size == 0:
+                break
+            vin[nb] = True
+            front = nb
+        f_ids = np.flatnonzero(fin)
+        vin[faces[f_ids].reshape(-1)] = True
+        fext.append(f_ids)
+        vext.append(np.flatnonzero(vin))
+    return fext, vext
+
+
+class _LocalMesh:
+    """The attributes :class:`loss.LossEngine` reads from a mesh (vs, fn, faces, f2f, edges), for a rank's sub-mesh."""
+
+
+class LossShard:
+    """One rank's sub-mesh for the sharded losses: local connectivity over [owned | ghost] rows (+ a copy of the mesh's
+    last face as the last local face, which is what the loss kernels gather for f2f == -1), the owned-row masks of the
+    partial sums, and the two ghost exchange plans (vertex positions, face normals)."""
+
+    def __init__(self, n_mesh, g: dict, rank: int, P: int, loop: int, owned_v: np.ndarray, owned_f: np.ndarray):
+        key = "loss_closures_%d" % loop
+        with _global_lock:
+            if key not in g:
+                g[key] = _loss_closures(n_mesh, g["face_owner"], g["vert_owner"], P, loop)
+        fext, vext = g[key]
+        faces = np.ascontiguousarray(n_mesh.faces, dtype=np.int64)
+        f2f = np.ascontiguousarray(n_mesh.f2f, dtype=np.int64)
+        V, F = len(n_mesh.vs), len(faces)
+        self.vplan = GhostPlan(vext, g["vert_owner"].astype(np.int64), rank, P, owned_v)
+        self.fplan = GhostPlan(fext, g["face_owner"].astype(np.int64), rank, P, owned_f)
+        v_ids, f_ids = self.vplan.local_ids, self.fplan.local_ids
+        nvl, nfl = len(v_ids), len(f_ids)
+        gv = np.full(V, -1, dtype=np.int64)
+        gv[v_ids] = np.arange(nvl)
+        gf = np.full(F, -1, dtype=np.int64)
+        gf[f_ids] = np.arange(nfl)
+        self.last_row = int(gf[F - 1])                                     # where the mesh's last face lives locally
+        f_all = np.concatenate([f_ids, [F - 1]])                           # + its copy, the last local face
+        lf = gv[faces[f_all]]
+        assert (lf >= 0).all()
+        l2 = f2f[f_all]
+        l2 = np.where(l2 >= 0, gf[np.maximum(l2, 0)], -1)                  # neighbours outside the closure: -1 (outermost
+        l2[-1] = -1                                                        # ghost ring only; those rows are never counted)
+        e = np.asarray(n_mesh.edges, dtype=np.int64)
+        le = gv[e]
+        le = le[(le >= 0).all(axis=1)]
+        m = _LocalMesh()
+        m.vs = np.asarray(n_mesh.vs, dtype=np.float64)[v_ids]
+        m.fn = np.asarray(n_mesh.fn, dtype=np.float64)[f_all]
+        m.faces, m.f2f, m.edges = lf, l2, le
+        m.vf_faces = nfl                                                   # the copy is not incident to anything
+        self.mesh = m
+        self.own_v = np.zeros(nvl, dtype=np.uint8)
+        self.own_v[: len(owned_v)] = 1
+        self.own_f = np.zeros(nfl + 1, dtype=np.uint8)
+        self.own_f[: len(owned_f)] = 1
+        self.V_glob, self.F_glob = V, F
+
+
 class ShardedData:
     """What a rank's two engines read: local slices of the static inputs + the two halo plans."""
 
@@ -449,6 +602,10 @@ class ShardedData:
         self.z2 = dataset.z2.detach().cpu()[torch.from_numpy(self.fplan.local_ids)]
         self.x_pos = dataset.x_pos.detach().cpu()[torch.from_numpy(self.vplan.owned)]
         self.V, self.F = V, F
+        self._g, self._n_mesh, self.rank, self.P = g, n_mesh, rank, P
+
+    def loss_shard(self, loop: int) -> "LossShard":
+        return LossShard(self._n_mesh, self._g, self.rank, self.P, loop, self.vplan.owned, self.fplan.owned)
 
 
 class DistributedTrainer:
@@ -456,7 +613,10 @@ class DistributedTrainer:
 
     def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
-                 bnf_start_epoch=100, ops_mod=None, loss_engine=None):
+                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None):
+        """``losses``: "sharded" (every rank evaluates the loss terms of its own rows on a ghost closure; two small
+        all-reduces of partial sums; default on the GPU) or "replicated" (one all-gather of pos | norm, every rank
+        runs the whole-mesh losses; what a caller-supplied ``loss_engine`` implies).  Env: DDMP_DIST_LOSSES."""
         from .engine import GcnEngine, POS_WIDTHS, NORM_WIDTHS
         self.ops = ops_mod or ops
         self.backend, self.device = backend, device
@@ -478,11 +638,31 @@ class DistributedTrainer:
                 net._engine = eng
         self.owned_v = torch.from_numpy(sd.vplan.owned).to(device)
         self.owned_f = torch.from_numpy(sd.fplan.owned).to(device)
-        self.full = torch.zeros((sd.V + sd.F + 1, 3), dtype=torch.float32, device=device)     # + the scratch row of the pads
-        self.gather_dst = torch.from_numpy(sd.gather_dst).to(device)
-        self.gather_send = torch.zeros((sd.gather_rows, 3), dtype=torch.float32, device=device)
-        self.gather_recv = torch.empty((backend.world_size * sd.gather_rows, 3), dtype=torch.float32, device=device)
-        if loss_engine is None:
+        import os
+        if losses is None:
+            losses = "replicated" if loss_engine is not None else os.environ.get("DDMP_DIST_LOSSES", "sharded")
+        if losses not in ("sharded", "replicated"):
+            raise ValueError("losses must be 'sharded' or 'replicated', got %r" % (losses,))
+        self.losses = losses
+        self._full = None                                        # pos | norm of the whole mesh: built when asked for
+        self._full_epoch = -1
+        if losses == "sharded":
+            from .loss import LossEngine
+            ls = sd.loss_shard(bnfloop)
+            self.lshard = ls
+            self.vghost, self.fghost = GraphComm(backend, ls.vplan, device), GraphComm(backend, ls.fplan, device)
+            f = dict(dtype=torch.float32, device=device)
+            # exchange buffers are 4 floats wide (16-byte rows: what the pack kernel / in-place receives move)
+            self.vbuf, self.fbuf = torch.zeros((ls.vplan.n_cols, 4), **f), torch.zeros((ls.fplan.n_cols, 4), **f)
+            self.pos_ext, self.norm_ext = torch.empty((ls.vplan.n_cols, 3), **f), torch.empty((ls.fplan.n_cols + 1, 3), **f)
+
+            class _Shard:
+                pass
+            sh = _Shard()
+            sh.own_v, sh.own_f = torch.from_numpy(ls.own_v).to(device), torch.from_numpy(ls.own_f).to(device)
+            sh.V_glob, sh.F_glob, sh.all_reduce = ls.V_glob, ls.F_glob, backend.all_reduce_sum
+            loss_engine = LossEngine(ls.mesh, device, bnfloop=bnfloop, k=k, shard=sh)
+        elif loss_engine is None:
             from .loss import LossEngine
             loss_engine = LossEngine(n_mesh, device, bnfloop=bnfloop, k=k)
         self.loss_engine = loss_engine
@@ -497,7 +677,6 @@ class DistributedTrainer:
         # DDMP_DIST_INTERLEAVE=1: the two nets alternate at their collectives (async_op=True).  Off by default: that
         # path has only run at world size 1 on RCCL and through gloo on CPU (no multi-GPU box in the build loop);
         # the default is the blocking form, which the threaded-rank GPU tests exercise kernel for kernel.
-        import os
         self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "0") == "1"
         if torch.device(device).type == "cuda" and os.environ.get("DDMP_ASYNC_WGRAD") == "1":
             self.peng.async_wgrad = self.neng.async_wgrad = True    # opt-in: weight gradients beside the dgrad chain
@@ -505,11 +684,51 @@ class DistributedTrainer:
     def barrier(self):
         self.backend.barrier()
 
+    def _assemble_full(self):
+        """pos | norm of the whole mesh on every rank: ONE all-gather of the owned rows (padded to the largest shard),
+        scattered to their global places.  COLLECTIVE: every rank has to call it (gather_pos / gather_norm / .pos /
+        .norm do) at the same point; cached until the next step."""
+        if self._full_epoch == self.epoch and self._full is not None:
+            return self._full
+        sd, dev = self.sd, self.device
+        if self._full is None:
+            self._full = torch.zeros((sd.V + sd.F + 1, 3), dtype=torch.float32, device=dev)   # + the scratch row of the pads
+            self._gather_dst = torch.from_numpy(sd.gather_dst).to(dev)
+            self._gather_send = torch.zeros((sd.gather_rows, 3), dtype=torch.float32, device=dev)
+            self._gather_recv = torch.empty((self.backend.world_size * sd.gather_rows, 3), dtype=torch.float32, device=dev)
+        pos_loc, norm_loc = self.peng.result, self.neng.result
+        nv, nf = pos_loc.shape[0], norm_loc.shape[0]
+        self._gather_send[:nv].copy_(pos_loc)
+        self._gather_send[nv:nv + nf].copy_(norm_loc)
+        self.backend.all_gather_rows(self._gather_recv, self._gather_send)
+        self._full.index_copy_(0, self._gather_dst, self._gather_recv)
+        self._full_epoch = self.epoch
+        return self._full
+
     def gather_pos(self):
-        return self.full[: self.sd.V]
+        with self.ops.on_device(self.device):
+            return self._assemble_full()[: self.sd.V]
 
     def gather_norm(self):
-        return self.full[self.sd.V: self.sd.V + self.sd.F]
+        with self.ops.on_device(self.device):
+            return self._assemble_full()[self.sd.V: self.sd.V + self.sd.F]
+
+    pos = property(gather_pos)
+    norm = property(gather_norm)
+
+    def _sharded_losses(self, pos_loc, norm_loc, gate):
+        """Ghost rows of pos / norm from their owners (two grouped exchanges), then this rank's share of the losses."""
+        ls = self.lshard
+        nv, nf = ls.vplan.n_rows, ls.fplan.n_rows
+        self.vbuf[:nv, :3].copy_(pos_loc)
+        self.fbuf[:nf, :3].copy_(norm_loc)
+        self.vghost.halo_exchange(self.vbuf, nv)
+        self.fghost.halo_exchange(self.fbuf, nf)
+        self.pos_ext.copy_(self.vbuf[:, :3])
+        self.norm_ext[:-1].copy_(self.fbuf[:, :3])
+        self.norm_ext[-1].copy_(self.norm_ext[ls.last_row])               # the copy of the mesh's last face
+        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(self.pos_ext, self.norm_ext, gate)
+        return lossbuf, dpos[:nv], dnorm[:nf]
 
     def check_scales(self) -> int:
         return self.peng.check_scales() + self.neng.check_scales()
@@ -533,23 +752,19 @@ class DistributedTrainer:
         else:
             self.peng.forward(pa, update_running=True)
             self.neng.forward(na, update_running=True)
-        # the losses are replicated: ONE all-gather of every rank's owned pos | norm rows (padded to the largest shard),
-        # scattered to their global places (half the bytes of the zero-fill + all-reduce it replaces)
-        pos_loc, norm_loc = self.peng.result, self.neng.result
-        nv, nf = pos_loc.shape[0], norm_loc.shape[0]
-        self.gather_send[:nv].copy_(pos_loc)
-        self.gather_send[nv:nv + nf].copy_(norm_loc)
-        self.backend.all_gather_rows(self.gather_recv, self.gather_send)
-        self.full.index_copy_(0, self.gather_dst, self.gather_recv)
-        pos, norm = self.full[:V], self.full[V:V + self.sd.F]
         gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
-        lossbuf, dpos, dnorm = self.loss_engine.forward_backward(pos, norm, gate)
-        if self.interleaved:
-            interleave(self.peng.backward_steps(pa, pg, dpos.index_select(0, self.owned_v)),
-                       self.neng.backward_steps(na, ng, dnorm.index_select(0, self.owned_f)))
+        if self.losses == "sharded":
+            lossbuf, dpos_loc, dnorm_loc = self._sharded_losses(self.peng.result, self.neng.result, gate)
         else:
-            self.peng.backward(pa, pg, dpos.index_select(0, self.owned_v))
-            self.neng.backward(na, ng, dnorm.index_select(0, self.owned_f))
+            # replicated: every rank runs the whole-mesh losses on the all-gathered pos | norm and keeps its rows
+            full = self._assemble_full()
+            lossbuf, dpos, dnorm = self.loss_engine.forward_backward(full[:V], full[V:V + self.sd.F], gate)
+            dpos_loc, dnorm_loc = dpos.index_select(0, self.owned_v), dnorm.index_select(0, self.owned_f)
+        if self.interleaved:
+            interleave(self.peng.backward_steps(pa, pg, dpos_loc), self.neng.backward_steps(na, ng, dnorm_loc))
+        else:
+            self.peng.backward(pa, pg, dpos_loc)
+            self.neng.backward(na, ng, dnorm_loc)
         self.posnet._reduce_grads()
         self.normnet._reduce_grads()
         o.grad_sumsq(ng, out=self.sumsq)
@@ -557,7 +772,6 @@ class DistributedTrainer:
         o.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
                      clip_sumsq=self.sumsq, max_norm=self.grad_crip)
         self.lossbuf = lossbuf
-        self.pos, self.norm = pos, norm
         return lossbuf[5]
 
 

@@ -61,8 +61,8 @@ class MeshTables:
         order = np.argsort(src, kind="stable")
         vv_ptr = np.zeros(V + 1, dtype=np.int64)
         np.cumsum(np.bincount(src, minlength=V), out=vv_ptr[1:])
-        flat = faces.reshape(-1)
-        corner = np.argsort(flat, kind="stable")                 # entries 3*f + k grouped by vertex
+        flat = faces[: getattr(mesh, "vf_faces", F)].reshape(-1)    # (a loss shard's trailing copy of the last face is
+        corner = np.argsort(flat, kind="stable")                 # incident to nothing)  entries 3*f + k grouped by vertex
         vf_ptr = np.zeros(V + 1, dtype=np.int64)
         np.cumsum(np.bincount(flat, minlength=V), out=vf_ptr[1:])
 
@@ -178,14 +178,15 @@ class _Scratch:
 
 
 # kernels ------------------------------------------------------------------------------------------
-def _vertex_fwd(tb, pos, real, s):
-    check(_lib.lib().ddmp_loss_vertex_fwd(tb.V, _p(pos), _p(real), _p(tb.vv_ptr), _p(tb.vv_idx), _p(s.resid),
-                                          _p(s.partials), _stream()), "ddmp_loss_vertex_fwd")
+def _vertex_fwd(tb, pos, real, s, own=None):
+    check(_lib.lib().ddmp_loss_vertex_fwd_part(tb.V, _p(pos), _p(real), _p(tb.vv_ptr), _p(tb.vv_idx), _p(s.resid),
+                                               _p(s.partials), _p(own), _stream()), "ddmp_loss_vertex_fwd")
 
 
-def _face_fwd(tb, pos, norm, real_n, s):
-    check(_lib.lib().ddmp_loss_face_fwd(tb.F, _p(pos), _p(norm), _p(real_n), _p(tb.faces), _p(s.fc), _p(s.fa),
-                                        _p(s.pn_coef), _p(s.pn_dn), _p(s.partials), _stream()), "ddmp_loss_face_fwd")
+def _face_fwd(tb, pos, norm, real_n, s, own=None):
+    check(_lib.lib().ddmp_loss_face_fwd_part(tb.F, _p(pos), _p(norm), _p(real_n), _p(tb.faces), _p(s.fc), _p(s.fa),
+                                             _p(s.pn_coef), _p(s.pn_dn), _p(s.partials), _p(own), _stream()),
+          "ddmp_loss_face_fwd")
 
 
 def _bnf_fwd(tb, norm, loop, s):
@@ -193,9 +194,21 @@ def _bnf_fwd(tb, norm, loop, s):
                                        _p(s.bnf_A), _p(s.partials), _stream()), "ddmp_loss_bnf_fwd")
 
 
-def _bnf_bwd(tb, loop, coef, s):
-    check(_lib.lib().ddmp_loss_bnf_bwd(tb.F, _p(tb.f2f), _p(s.fa), _p(s.fcd), loop, _p(s.bnf_n), _p(s.bnf_A),
-                                       _p(s.partials), _p(coef), _p(s.G0), _p(s.scr), _stream()), "ddmp_loss_bnf_bwd")
+def _bnf_fwd_sharded(tb, norm, loop, s, sh):
+    """fn_bnf_loss forward on a shard: sigma_c is a mean over ALL faces, so its partial sums are all-reduced between
+    the distance pass and the filter passes; the filter divides by the global face count."""
+    L = _lib.lib()
+    check(L.ddmp_loss_bnf_sigma(tb.F, _p(norm), _p(tb.f2f), _p(s.fc), _p(s.fcd), _p(s.bnf_n), _p(s.partials),
+                                _p(sh.own_f), _stream()), "ddmp_loss_bnf_sigma")
+    sh.all_reduce(s.partials.view(6, -1)[_P["SIG"]])
+    check(L.ddmp_loss_bnf_filter(tb.F, sh.F_glob, _p(tb.f2f), _p(s.fcd), _p(s.fa), loop, _p(s.bnf_n), _p(s.bnf_A),
+                                 _p(s.partials), _p(sh.own_f), _stream()), "ddmp_loss_bnf_filter")
+
+
+def _bnf_bwd(tb, loop, coef, s, F_glob=None):
+    check(_lib.lib().ddmp_loss_bnf_bwd_part(tb.F, tb.F if F_glob is None else F_glob, _p(tb.f2f), _p(s.fa), _p(s.fcd),
+                                            loop, _p(s.bnf_n), _p(s.bnf_A), _p(s.partials), _p(coef), _p(s.G0),
+                                            _p(s.scr), _stream()), "ddmp_loss_bnf_bwd")
 
 
 def _face_bwd(tb, norm, real_n, coef, s, with_bnf, loop, out):
@@ -413,7 +426,12 @@ def angular_difference(norm1, norm2):
 class LossEngine:
     """All five losses + gradients with device-side scalars (main.py:94-106 in one go)."""
 
-    def __init__(self, mesh, device, bnfloop=1, k=(3.0, 4.0, 4.0, 4.0, 1.0)):
+    def __init__(self, mesh, device, bnfloop=1, k=(3.0, 4.0, 4.0, 4.0, 1.0), shard=None):
+        """``shard`` (multi-GPU, dist.DistributedTrainer): ``mesh`` is the rank's sub-mesh (dist.LossShard.mesh) and
+        ``shard`` carries ``own_v`` / ``own_f`` (uint8 device masks of the rows whose terms this rank sums), the global
+        ``V_glob`` / ``F_glob`` and ``all_reduce(tensor)``; the loss VALUES that come back are the global ones, the
+        gradients are exact on the owned rows (ghost rows hold partial sums and are dropped by the caller)."""
+        self.shard = shard
         self.tb = tables_for(mesh, device)
         self.real_pos = _target(mesh.vs, device)
         self.real_norm = _target(mesh.fn, device)
@@ -426,18 +444,26 @@ class LossEngine:
         """-> (lossbuf [12] float64 device, dpos [V,3], dnorm [F,3]).  ``gate4`` = 0.0 while epoch <= 100
         (main.py:101-102).  The BNF value is always computed; its backward is skipped when k4*gate4 == 0
         (the reference back-propagates a zero there)."""
-        tb, s, loop = self.tb, self.s, self.loop
+        tb, s, loop, sh = self.tb, self.s, self.loop, self.shard
         with _timed("loss_fwd", loop):
-            _vertex_fwd(tb, pos, self.real_pos, s)
-            _face_fwd(tb, pos, norm, self.real_norm, s)
-            _bnf_fwd(tb, norm, loop, s)
-            check(_lib.lib().ddmp_loss_finalize(_p(s.partials), tb.V, tb.F, self.k, float(gate4), _p(s.lossbuf), _stream()),
+            if sh is None:
+                _vertex_fwd(tb, pos, self.real_pos, s)
+                _face_fwd(tb, pos, norm, self.real_norm, s)
+                _bnf_fwd(tb, norm, loop, s)
+                Vg, Fg = tb.V, tb.F
+            else:
+                _vertex_fwd(tb, pos, self.real_pos, s, sh.own_v)
+                _face_fwd(tb, pos, norm, self.real_norm, s, sh.own_f)
+                _bnf_fwd_sharded(tb, norm, loop, s, sh)
+                sh.all_reduce(s.partials.view(6, -1)[:_P["SIG"]])         # S1..S5 (sigma_c is global already)
+                Vg, Fg = sh.V_glob, sh.F_glob
+            check(_lib.lib().ddmp_loss_finalize(_p(s.partials), Vg, Fg, self.k, float(gate4), _p(s.lossbuf), _stream()),
                   "ddmp_loss_finalize")
         coef = s.lossbuf[6:11]
         with_bnf = (self.k_list[3] * gate4) != 0.0
         with _timed("loss_bwd", loop if with_bnf else 0):
             if with_bnf:
-                _bnf_bwd(tb, loop, coef, s)
+                _bnf_bwd(tb, loop, coef, s, None if sh is None else sh.F_glob)
             _face_bwd(tb, norm, self.real_norm, coef, s, with_bnf, loop, s.dnorm)
             _vertex_bwd(tb, pos, self.real_pos, norm, coef, s, s.dpos)
         return s.lossbuf, s.dpos, s.dnorm

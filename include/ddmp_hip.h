@@ -203,6 +203,29 @@ int ddmp_loss_vertex_bwd(int64_t V, const float* pos, const double* real_pos, co
                          const int32_t* vf_corner, const float* pn_coef, const float* norm, const double* coef,
                          float* dpos /*[V,3]*/, ddmp_stream stream);
 
+/* Sharded form of the same losses (one rank of a partitioned mesh).  The rank runs the kernels above on its
+ * LOCAL sub-mesh = owned vertices / faces plus a ghost closure deep enough that every value an owned row's loss term or
+ * gradient reads is computed locally (dist.LossShard: 2*loop+1 face rings, 2 vertex rings, the mesh's last face for the
+ * "-1" slots): no exchange inside the losses.  What differs from the single-device calls:
+ *   - `own` (uint8 per local row, nullable = all): partial sums count owned rows only; ghost rows are computed, not counted;
+ *   - the caller all-reduces the partial sums across ranks -- the sigma_c slice between ddmp_loss_bnf_sigma and
+ *     ddmp_loss_bnf_filter, the S1..S5 slices before ddmp_loss_finalize (which takes the GLOBAL V, F);
+ *   - F_glob: sigma_c = sum / (3 F_glob) is a mean over all faces of the mesh; the local F still addresses the local
+ *     "last face" (the caller places the mesh's last face at the end of its local numbering).
+ * partials layout: 6 slices of ddmp_loss_partials_bytes() / 48 doubles: S1..S5, sigma_c. */
+int ddmp_loss_vertex_fwd_part(int64_t V, const float* pos, const double* real_pos, const int32_t* vv_ptr,
+                              const int32_t* vv_idx, float* resid, double* partials, const uint8_t* own, ddmp_stream stream);
+int ddmp_loss_face_fwd_part(int64_t F, const float* pos, const float* norm, const double* real_norm, const int32_t* faces,
+                            float* fc, float* fa, float* pn_coef, float* pn_dn, double* partials, const uint8_t* own,
+                            ddmp_stream stream);
+int ddmp_loss_bnf_sigma(int64_t F, const float* norm, const int32_t* f2f, const float* fc, float* fcd, float* bnf_n,
+                        double* partials, const uint8_t* own, ddmp_stream stream);
+int ddmp_loss_bnf_filter(int64_t F, int64_t F_glob, const int32_t* f2f, const float* fcd, const float* fa, int loop,
+                         float* bnf_n, float* bnf_A, double* partials, const uint8_t* own, ddmp_stream stream);
+int ddmp_loss_bnf_bwd_part(int64_t F, int64_t F_glob, const int32_t* f2f, const float* fa, const float* fcd, int loop,
+                           const float* bnf_n, const float* bnf_A, const double* partials, const double* coef, float* G0,
+                           float* scratch, ddmp_stream stream);
+
 /* ------------------------------------------------------------------ clip_grad_norm_ + Adam (main.py:108-110)
  * One flat float32 arena per net for param / grad / exp_avg / exp_avg_sq.  clip: coefficient
  * min(1, max_norm / (sqrt(sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_); Adam: torch defaults

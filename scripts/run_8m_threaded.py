@@ -52,7 +52,7 @@ def work(r):
         tb = time.perf_counter()
         loss2 = t.step().item()
         res[r] = (loss, loss2, tb - ta, time.perf_counter() - tb, t.peng.n_rows, t.peng.n_cols, t.neng.n_rows, t.neng.n_cols,
-                  t.gather_pos().clone() if r == 0 else None)
+                  (lambda g: g.clone() if r == 0 else None)(t.gather_pos()))       # collective: every rank calls it
     except BaseException as e:      # noqa: BLE001
         import traceback; traceback.print_exc()
         errs.append(e)

@@ -212,3 +212,57 @@ def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave):
     for r in range(2):
         _compare(ref[0], got[r], ref, "gloo rank%d" % r)
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize("P,kind,loop", [(2, "ico2", 1), (3, "grid", 1), (4, "grid", 2)])
+def test_loss_shard_closure_and_exchange(P, kind, loop):
+    """dist.LossShard: the local sub-mesh maps back to the global one, owned rows see their full neighbourhoods, the mesh's
+    last face is the last local face, and the ghost exchange schedules of the ranks agree with each other."""
+    from dual_dmp_amd import dist as D
+    noisy, smooth, data = _mesh(kind)
+    faces, f2f = np.asarray(noisy.faces, dtype=np.int64), np.asarray(noisy.f2f, dtype=np.int64)
+    V, F = len(noisy.vs), len(faces)
+    sds = [D.ShardedData(data, noisy, r, P) for r in range(P)]
+    shards = [sd.loss_shard(loop) for sd in sds]
+    nbrs = [set() for _ in range(V)]
+    for a, b in np.asarray(noisy.edges):
+        nbrs[a].add(int(b)); nbrs[b].add(int(a))
+    for r, (sd, ls) in enumerate(zip(sds, shards)):
+        m, vp, fp = ls.mesh, ls.vplan, ls.fplan
+        nv, nf = vp.n_rows, fp.n_rows
+        assert np.array_equal(vp.local_ids[:nv], sd.vplan.owned) and np.array_equal(fp.local_ids[:nf], sd.fplan.owned)
+        f_all = np.concatenate([fp.local_ids, [F - 1]])
+        assert np.array_equal(vp.local_ids[m.faces], faces[f_all])                 # corners map back
+        assert len(m.faces) == fp.n_cols + 1 and ls.own_f[-1] == 0 and fp.local_ids[ls.last_row] == F - 1
+        assert ls.own_v.sum() == nv and ls.own_f.sum() == nf and ls.own_v[:nv].all() and ls.own_f[:nf].all()
+        # rows within 2*loop rings of an owned face keep their three neighbours (or the -1 of an open boundary)
+        ring = set(sd.fplan.owned.tolist())
+        front = set(ring)
+        for _ in range(2 * loop):
+            front = {int(j) for i in front for j in f2f[i] if j >= 0} - ring
+            ring |= front
+        gl = {int(gid): li for li, gid in enumerate(fp.local_ids)}
+        for gid in ring:
+            loc = m.f2f[gl[gid]]
+            back = np.where(loc >= 0, f_all[np.maximum(loc, 0)], -1)
+            assert np.array_equal(back, f2f[gid]), (r, gid)
+        # vertex tables: an owned vertex and its neighbours keep their full edge sets; owned vertices keep all faces
+        vl = {int(gid): li for li, gid in enumerate(vp.local_ids)}
+        loc_nb = [set() for _ in range(len(vp.local_ids))]
+        for a, b in m.edges:
+            loc_nb[a].add(int(vp.local_ids[b])); loc_nb[b].add(int(vp.local_ids[a]))
+        for gid in sd.vplan.owned:
+            for u in [int(gid)] + sorted(nbrs[gid]):
+                assert loc_nb[vl[u]] == nbrs[u], (r, gid, u)
+            inc = {int(i) for i in np.flatnonzero((faces == gid).any(axis=1))}
+            assert inc <= set(fp.local_ids.tolist())
+        # what r receives from s is what s sends to r, in the same order
+        for plans, mine in (([x.vplan for x in shards], vp), ([x.fplan for x in shards], fp)):
+            off = 0
+            for s in range(P):
+                cnt = mine.recv_counts[s]
+                q = plans[s]
+                s0 = sum(q.send_counts[:r])
+                assert q.send_counts[r] == cnt
+                assert np.array_equal(q.owned[q.send_idx[s0:s0 + cnt]], mine.halo[off:off + cnt])
+                off += cnt

@@ -67,3 +67,67 @@ def test_partitioned_step_matches_single_device(P, kind):
         assert torch.equal(tr.normnet.arena.data, results[0][1].normnet.arena.data)
     assert sum(results[r][1].peng.n_rows for r in range(P)) == len(noisy.vs)
     assert sum(results[r][1].neng.n_rows for r in range(P)) == len(noisy.faces)
+
+
+@pytest.mark.parametrize("P,kind,loop,partition", [(2, "ico3", 1, "morton"), (4, "ico3", 3, "morton"), (3, "grid", 2, "morton"),
+                                                   (4, "grid", 1, "random"), (3, "ico3", 2, "random")])
+def test_sharded_losses_match_whole_mesh_losses(P, kind, loop, partition):
+    """Every rank evaluates the loss terms of its own rows on its ghost closure (dist.LossShard): the twelve loss scalars
+    and the gradient rows each rank keeps must be those of the whole-mesh LossEngine on the same pos / norm -- closed
+    mesh and open mesh (f2f == -1 -> the mesh's LAST face), Morton chunks and a scattered (worst-case) ownership."""
+    from dual_dmp_amd import synth, dist as D
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.loss import LossEngine
+    dev = torch.device("cuda:0")
+    v, f = synth.icosphere(3) if kind == "ico3" else synth.open_grid(20, 15)
+    v, f = synth.permute_vertices(v, f, 4)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+    V, F = len(noisy.vs), len(noisy.faces)
+    g = torch.Generator().manual_seed(7)
+    pos = (torch.from_numpy(np.asarray(smooth.vs, dtype=np.float32)) + 0.02 * torch.randn(V, 3, generator=g)).to(dev)
+    norm = torch.nn.functional.normalize(torch.from_numpy(np.asarray(noisy.fn, dtype=np.float32)) + 0.3 * torch.randn(F, 3, generator=g), dim=1).to(dev)
+    whole = LossEngine(noisy, dev, bnfloop=loop)
+    lb, dp, dn = whole.forward_backward(pos, norm, 1.0)
+    lb, dp, dn = lb.clone(), dp.clone(), dn.clone()
+    owner = None
+    if partition == "random":
+        owner = np.random.RandomState(3).randint(0, P, size=F).astype(np.int32)
+    nets = []
+    for _ in range(P):
+        torch.manual_seed(0)
+        nets.append((PosNet(dev), NormalNet(dev)))
+    comms = D.ThreadComm.make(P)
+    res, errs = {}, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            sd = D.ShardedData(data, noisy, r, P, face_owner=owner)
+            tr = D.DistributedTrainer(nets[r][0], nets[r][1], sd, noisy, comms[r], dev, bnfloop=loop, losses="sharded")
+            ov, of = torch.from_numpy(sd.vplan.owned).to(dev), torch.from_numpy(sd.fplan.owned).to(dev)
+            with D.ops.on_device(dev):
+                l, a, b = tr._sharded_losses(pos[ov].contiguous(), norm[of].contiguous(), 1.0)
+            res[r] = (l.clone(), a.clone(), b.clone(), ov, of, tr.lshard)
+        except BaseException as e:       # noqa: BLE001
+            errs.append(e)
+            comms[r].s.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    seen_v, seen_f = torch.zeros(V, dtype=torch.bool, device=dev), torch.zeros(F, dtype=torch.bool, device=dev)
+    for r in range(P):
+        l, a, b, ov, of, ls = res[r]
+        # the sums are float64 over a different association of the same float32 terms
+        assert torch.allclose(l, lb, rtol=1e-9, atol=1e-12), (r, l, lb)
+        sa, sb = float(dp.abs().max()), float(dn.abs().max())
+        assert float((a - dp[ov]).abs().max()) <= 2e-6 * sa, (r, float((a - dp[ov]).abs().max()), sa)
+        assert float((b - dn[of]).abs().max()) <= 2e-6 * sb, (r, float((b - dn[of]).abs().max()), sb)
+        seen_v[ov] = True
+        seen_f[of] = True
+        if partition == "morton" and loop == 1:
+            assert ls.vplan.n_cols < V and ls.fplan.n_cols < F                     # a closure, not the whole mesh
+    assert bool(seen_v.all()) and bool(seen_f.all())

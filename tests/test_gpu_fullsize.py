@@ -236,7 +236,7 @@ def test_8m_faces_eight_ranks_bf16_features():
             torch.cuda.set_device(0)
             t = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, backend=comms[r], nets=nets[r])
             res[r] = (t.step().item(), t.peng.n_rows, t.peng.n_cols, t.neng.n_rows, t.neng.n_cols,
-                      t.gather_pos().clone() if r == 0 else None)
+                      (lambda g: g.clone() if r == 0 else None)(t.gather_pos()))       # collective: every rank calls it
         except BaseException as e:      # noqa: BLE001
             errs.append(e)
             comms[r].s.barrier.abort()
