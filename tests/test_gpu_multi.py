@@ -1,0 +1,27 @@
+"""One process per GPU over RCCL against the single-device trainer ("a 2-GPU torchrun nccl parity test ...
+covering both interleave settings").  Uses min(2, visible GPUs) ranks: on a one-GPU box this is the RCCL path at world
+size 1 (communicator, all_to_all_single with empty splits, all-reduces, ghost exchanges); on a multi-GPU box the halos,
+ghost rows and partial sums really travel."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("kind,losses,interleave,native", [("ico4", "sharded", "0", "0"), ("grid", "sharded", "1", "0"),
+                                                           ("ico4", "replicated", "1", "0"), ("grid", "sharded", "0", "1")])
+def test_rccl_ranks_match_single_device(kind, losses, interleave, native):
+    n = min(2, torch.cuda.device_count())                   # counting devices does not initialise the GPU in this process
+    assert n >= 1
+    env = dict(os.environ, DDMP_DIST_INTERLEAVE=interleave, DDMP_DIST_NATIVE=native, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() + hash((kind, losses, interleave, native))) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "nccl_worker.py"), kind, losses, "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "PARITY" in r.stdout, tail
