@@ -105,8 +105,23 @@ class ArenaLayout:
         add("linear2.bias", (3,))
         self.total = off
         self.index = {e[0]: e for e in self.entries}
+        self._views = {}
 
     def view(self, arena: torch.Tensor, name: str, true_shape=True):
+        # the engines ask for the same ~60 views of the same two arenas every iteration: cached per arena storage
+        # (the cached view keeps its storage alive, so an address cannot be handed to another arena meanwhile)
+        if arena.requires_grad:
+            return self._make_view(arena, name, true_shape)
+        key = (arena.data_ptr(), arena.numel(), name, true_shape)
+        v = self._views.get(key)
+        if v is None:
+            v = self._make_view(arena, name, true_shape)
+            if len(self._views) > 1024:
+                self._views.clear()
+            self._views[key] = v
+        return v
+
+    def _make_view(self, arena: torch.Tensor, name: str, true_shape=True):
         _, off, stored, true = self.index[name]
         n = 1
         for s in stored:
