@@ -184,11 +184,14 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(name, dtype):
+def pmc_traffic(name, dtype, launches_per_step):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes of this same command
     (profiles/*_pmc_hbm_traffic*.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate --pmc passes,
     scripts/pmc_traffic.py).  bench.py cannot run the profiler itself.  A file measured on OTHER kernel sources (its
-    csrc_sha16 differs from the tree's) or for the other feature dtype is refused: (None, reason)."""
+    csrc_sha16 differs from the tree's) or for the other feature dtype is refused: (None, reason).
+    Per launch = the family's bytes per profiled iteration / the C-ABI calls per iteration counted by THIS run: a call of the
+    f16x3 GEMMs enqueues a second ("heal") kernel that returns at once and moves nothing, which would halve a per-dispatch
+    average."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic*.json")))
     files = [f for f in files if json.load(open(f)).get("dtype", "f32") == dtype]
@@ -198,6 +201,9 @@ def pmc_traffic(name, dtype):
     if d.get("csrc_sha16") != csrc_sha16():
         return None, "stale: %s was measured on other kernel sources (csrc %s, tree %s)" % (
             os.path.basename(files[-1]), d.get("csrc_sha16"), csrc_sha16())
+    iters = float(d.get("iterations", 0))
+    if iters <= 0 or not launches_per_step:
+        return None, "%s does not record its iteration count" % os.path.basename(files[-1])
     tot_b = tot_n = 0.0
     for k in d.get("per_kernel", []):
         kn = k["kernel"]
@@ -207,12 +213,14 @@ def pmc_traffic(name, dtype):
         if fam == want or (name == "gemm" and fam.startswith("gemm_")):
             tot_b += (k["hbm_read_GB"] + k["hbm_write_GB"]) * 1e9
             tot_n += k["launches"]
-    return (round(tot_b / tot_n), os.path.basename(files[-1])) if tot_n else (None, "kernel family not in " + os.path.basename(files[-1]))
+    if not tot_n:
+        return None, "kernel family not in " + os.path.basename(files[-1])
+    return round(tot_b / iters / launches_per_step), os.path.basename(files[-1])
 
 
 def roofline_obj(name, f, dtype):
     ms = f["ms"]
-    tb, tsrc = pmc_traffic(name, dtype)
+    tb, tsrc = pmc_traffic(name, dtype, f["calls"])
     if name.startswith("gemm"):
         from dual_dmp_amd import ops
         mode = ops.get_gemm_mode()

@@ -21,7 +21,7 @@ DB=$(ls $O/${TAG}${SUF}_prof/*/*results.db $O/${TAG}${SUF}_prof/*results.db 2>/d
 python3 scripts/rocpd_summary.py "$DB" --top 60 > $O/${TAG}${SUF}_bench_kernel_stats.txt 2>> $O/${TAG}${SUF}_prof.log
 FD=$(ls $O/${TAG}${SUF}_pmc_F/*/*results.db $O/${TAG}${SUF}_pmc_F/*results.db 2>/dev/null | head -1)
 WD=$(ls $O/${TAG}${SUF}_pmc_W/*/*results.db $O/${TAG}${SUF}_pmc_W/*results.db 2>/dev/null | head -1)
-python3 scripts/pmc_traffic.py "$FD" "$WD" "bench.py $PROF (4 eager iterations per pass)" $DT > $O/${TAG}${SUF}_pmc_hbm_traffic.json 2>> $O/${TAG}${SUF}_prof.log
+python3 scripts/pmc_traffic.py "$FD" "$WD" "bench.py $PROF (4 eager iterations per pass)" $DT 4 > $O/${TAG}${SUF}_pmc_hbm_traffic.json 2>> $O/${TAG}${SUF}_prof.log
 # keep the merge-back small: the raw databases stay on the box
 rm -rf $O/${TAG}${SUF}_prof $O/${TAG}${SUF}_pmc_F $O/${TAG}${SUF}_pmc_W
 ls -la $O | grep ${TAG}${SUF}

@@ -2,7 +2,7 @@
 """HBM traffic per kernel from two rocprofv3 PMC passes (rocpd sqlite) of the same command:
       rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_F -o r -- python3 bench.py ...
       rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_W -o r -- python3 bench.py ...
-   usage: pmc_traffic.py <fetch.db> <write.db> [note] [dtype] > profiles/rNN_pmc_hbm_traffic[_bf16].json
+   usage: pmc_traffic.py <fetch.db> <write.db> [note] [dtype] [iterations] > profiles/rNN_pmc_hbm_traffic[_bf16].json
 The output records the content hash of the kernel sources it was measured on (csrc_sha16) and the feature dtype:
 bench.py quotes a traffic figure only for the tree it belongs to.
 Units (MI355X_MICROARCH.md): both counters are in KB (x1024); FETCH_SIZE is doubled on gfx950, which reports half of the
@@ -58,6 +58,7 @@ def main():
     w, _ = per_kernel(sys.argv[2], "WRITE_SIZE")
     note = sys.argv[3] if len(sys.argv) > 3 else ""
     dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
+    iterations = int(sys.argv[5]) if len(sys.argv) > 5 else 4             # steps + warmup of the profiled command
     import os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import bench
@@ -76,7 +77,7 @@ def main():
         a["kernel_ms"] = round(a["kernel_ms"] + r["ms"], 2)
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); bytes = KB*1024, FETCH_SIZE doubled per "
                        "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads). " + note,
-               "dtype": dtype, "csrc_sha16": bench.csrc_sha16(), "per_family": fam, "per_kernel": rows[:40]}, sys.stdout, indent=1)
+               "dtype": dtype, "iterations": iterations, "csrc_sha16": bench.csrc_sha16(), "per_family": fam, "per_kernel": rows[:40]}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
