@@ -439,6 +439,26 @@ def main():
         del tr2
         torch.cuda.empty_cache()
 
+    # ---- what a plain device copy (half read, half write: the traffic shape of a gather or a row-panel GEMM) reaches on THIS
+    # box: context for the fractions of the 8 TB/s peak above (outside the timed region)
+    if rank == 0:
+        src = torch.empty(512 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()        # 2 GiB read + 2 GiB written
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+        for r_ in (roof, roof_gather):
+            if isinstance(r_, dict) and r_.get("bound") == "hbm":
+                r_["device_copy_GBs"] = round(copy_gbs, 1)
+                r_["frac_of_device_copy"] = round(r_["achieved"] / copy_gbs, 4)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_sample_faces, F, args.cpu_iters)
