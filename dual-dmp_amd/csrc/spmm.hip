@@ -491,6 +491,19 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 }
 
 #include "fpartials.inc"
+#include "spmm_lean.inc"
+
+template <bool PRO, bool RED, bool BWD>
+int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                const float* bias, const float* ps, const float* psh, float slope, hipStream_t st, BnRed red = BnRed(),
+                BnBwdGather bwd = BnBwdGather()) {
+    const int n = (int)g->n_rows;
+    const int cpx = (int)cdiv(lp.n_chunks, kXcd);
+    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
+                       Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, lp.stride, red, bwd);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
 
 template <int LANES, int U, int NR, int SL = 1>
 int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
@@ -499,6 +512,11 @@ int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int6
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     dim3 grid(cpx * kXcd), block(256);
+    if (LANES == 8 && U == 4 && NR == 1 && SL == 1) {
+        const LeanPlan lp = lean_plan(g, ldx, C);
+        if (lp.kind && ps) return launch_lean<true, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
+        if (lp.kind) return launch_lean<false, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
+    }
     if (ps)
         hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
@@ -643,12 +661,20 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
         }
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
-    hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
-                       g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       slope, cpx, n_chunks, red);
-    LAUNCH_TRY();
+    int red_chunks = n_chunks;
+    const LeanPlan lp = lean_plan(g, ldx, C);
+    if (lp.kind) {
+        const int rc = launch_lean<false, true, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
+        if (rc != DDMP_OK) return rc;
+        red_chunks = lp.n_chunks;
+    } else {
+        hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
+                           g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           slope, cpx, n_chunks, red);
+        LAUNCH_TRY();
+    }
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    fpartials_reduce((const float*)ws, red_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -669,6 +695,8 @@ extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnBwdGather bwd{Yb, ldyb, c1, c0};
+    const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, C) : LeanPlan{0, 0, 0};   // one staged offset serves both matrices
+    if (lp.kind) return launch_lean<true, false, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
                        (hipStream_t)stream, g->rowptr, g->col, g->dinv, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,
                        a, b, slope, cpx, n_chunks, BnRed(), bwd);

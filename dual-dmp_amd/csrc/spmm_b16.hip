@@ -63,20 +63,27 @@ template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f
 
 // LANES lanes x VW channels per row and slab (128-byte slabs: LANES x VW = 64; narrower rows: fewer lanes).
 // VW = 8 (16-byte pieces) by default; VW = 4 exists for A/B runs of the fused forms (see dispatch_b16).
-template <int VW, int LANES, int U, bool PRO, bool RED, bool BWD>
+// LEAN (default; see spmm_lean.inc for the measurements): everything that does not depend on the slab is done once per chunk
+// at staging time -- an entry is (row offset in 16-byte units, weight), rows own fixed slots of `stride` entries padded to
+// whole quads with weight-0 copies of their last entry -- so the address of a gathered piece is one v_lshl_add_u64 on the
+// lane's slab base and the inner loop reads four entries with two ds_read_b128, without clamping or branches.
+template <int VW, int LANES, int U, bool PRO, bool RED, bool BWD, bool LEAN>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int chunks_per_xcd, int n_chunks, BnRedB red, BnBwdGatherB bwd) {
+    float slope, int chunks_per_xcd, int n_chunks, int stride, BnRedB red, BnBwdGatherB bwd) {
     static_assert(!BWD || (PRO && !RED), "BWD: the coefficients a, b come as the prologue's");
+    static_assert(!LEAN || U == 4, "quads");
     typedef Piece<VW> PC;
     constexpr int CS = LANES * VW;
     constexpr int RPW = 64 / LANES;
     constexpr int RPB = 4 * RPW;
     __shared__ int s_rowptr[kRB + 1];
-    __shared__ int s_col[kMaxE];
-    __shared__ float s_w[kMaxE];
+    __shared__ int s_quads[kRB];
+    __shared__ __attribute__((aligned(16))) uint2 s_ent[kMaxE];  // LEAN: (offset, weight) slots; else: s_col | s_w
+    int* s_col = reinterpret_cast<int*>(s_ent);
+    float* s_w = reinterpret_cast<float*>(s_ent) + kMaxE;
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -88,7 +95,21 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int e0 = s_rowptr[0];
     const int ne = s_rowptr[nr] - e0;
     const bool staged = ne <= kMaxE;
-    if (staged) {
+    if (LEAN) {
+        const unsigned ld16 = (unsigned)(ldx >> 3);              // row pitch in 16-byte units
+        for (int i = tid; i < nr * stride; i += 256) {
+            const int lr = i / stride, k = i - lr * stride;
+            const int rb = s_rowptr[lr], nn = s_rowptr[lr + 1] - rb;
+            uint2 e = make_uint2(0u, 0u);
+            if (nn > 0) {                                        // padding: the row's last entry again, weight 0
+                const int c = col[rb + min(k, nn - 1)];
+                e.x = (unsigned)c * ld16;
+                e.y = k < nn ? __float_as_uint(dinv[c]) : 0u;
+            }
+            s_ent[i] = e;
+            if (k == 0) s_quads[lr] = (nn + 3) >> 2;
+        }
+    } else if (staged) {
         for (int t = tid; t < ne; t += 256) {
             const int c = col[e0 + t];
             s_col[t] = c;
@@ -125,31 +146,47 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         const bf16_t* xc = X + off;
         const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
         for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
-            int es = s_rowptr[lr] - e0;
-            const int ee = s_rowptr[lr + 1] - e0;
+            int es = LEAN ? 0 : s_rowptr[lr] - e0;
+            const int ee = LEAN ? 4 * s_quads[lr] : s_rowptr[lr + 1] - e0;
+            const uint4* ep = reinterpret_cast<const uint4*>(&s_ent[LEAN ? lr * stride : 0]);
             float acc[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) acc[j] = 0.f;
             while (es < ee) {
                 int cj[U];
                 float wj[U];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int ek = min(es + k, ee - 1);
-                    if (staged) {
-                        cj[k] = s_col[ek];
-                        wj[k] = s_w[ek];
-                    } else {
-                        cj[k] = col[e0 + ek];
-                        wj[k] = dinv[cj[k]];
-                    }
-                    if (es + k >= ee) wj[k] = 0.f;
-                }
                 typename PC::raw v[U], vy[BWD ? U : 1];
+                if (LEAN) {
+                    const uint4 ea = ep[es >> 1], eb = ep[(es >> 1) + 1];
+                    const unsigned o[4] = {ea.x, ea.z, eb.x, eb.z};
+                    wj[0] = __uint_as_float(ea.y);
+                    wj[1] = __uint_as_float(ea.w);
+                    wj[2] = __uint_as_float(eb.y);
+                    wj[U - 1] = __uint_as_float(eb.w);
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    v[k] = PC::ld(xc + (int64_t)cj[k] * ldx);
-                    if (BWD) vy[BWD ? k : 0] = PC::ld(yc + (int64_t)cj[k] * bwd.ldyb);
+                    for (int k = 0; k < U; ++k) {
+                        const uint64_t bo = (uint64_t)o[k & 3] << 4;
+                        v[k] = PC::ld(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(xc) + bo));
+                        if (BWD) vy[BWD ? k : 0] = PC::ld(reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(yc) + bo));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const int ek = min(es + k, ee - 1);
+                        if (staged) {
+                            cj[k] = s_col[ek];
+                            wj[k] = s_w[ek];
+                        } else {
+                            cj[k] = col[e0 + ek];
+                            wj[k] = dinv[cj[k]];
+                        }
+                        if (es + k >= ee) wj[k] = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        v[k] = PC::ld(xc + (int64_t)cj[k] * ldx);
+                        if (BWD) vy[BWD ? k : 0] = PC::ld(yc + (int64_t)cj[k] * bwd.ldyb);
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
@@ -220,8 +257,21 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
-    hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
-                       g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red, bwd);
+    // lean staging where the rows fit their slots and the offsets (16-byte units) fit 32 bits; DDMP_SPMM_LEAN=0 for A/B
+    static int lean_on = -1;
+    if (lean_on < 0) {
+        const char* e = getenv("DDMP_SPMM_LEAN");
+        lean_on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    const bool lean = lean_on && g->max_row_nnz >= 1 && g->max_row_nnz <= 16 && (ldx & 7) == 0 &&
+                      (uint64_t)g->n_cols * (uint64_t)(ldx >> 3) < (1ull << 32) && (!BWD || bwd.ldyb == ldx);
+    const int stride = (g->max_row_nnz + 3) & ~3;
+    if (lean)
+        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, stride, red, bwd);
+    else
+        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, false>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, stride, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }
