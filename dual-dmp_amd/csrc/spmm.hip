@@ -513,7 +513,7 @@ int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int6
     const int cpx = (int)cdiv(n_chunks, kXcd);
     dim3 grid(cpx * kXcd), block(256);
     if (LANES == 8 && U == 4 && NR == 1 && SL == 1) {
-        const LeanPlan lp = lean_plan(g, ldx, C);
+        const LeanPlan lp = lean_plan(g, ldx, ldy, C);
         if (lp.kind && ps) return launch_lean<true, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
         if (lp.kind) return launch_lean<false, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
     }
@@ -662,7 +662,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
     int red_chunks = n_chunks;
-    const LeanPlan lp = lean_plan(g, ldx, C);
+    const LeanPlan lp = lean_plan(g, ldx, ldy, C, 2);
     if (lp.kind) {
         const int rc = launch_lean<false, true, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
         if (rc != DDMP_OK) return rc;
@@ -695,7 +695,7 @@ extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnBwdGather bwd{Yb, ldyb, c1, c0};
-    const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, C) : LeanPlan{0, 0, 0};   // one staged offset serves both matrices
+    const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, ld_out, C, 4) : LeanPlan{0, 0, 0};   // one staged offset serves both matrices
     if (lp.kind) return launch_lean<true, false, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
                        (hipStream_t)stream, g->rowptr, g->col, g->dinv, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,

@@ -454,3 +454,48 @@ def test_no_cpu_fallback():
     from dual_dmp_amd import ops, _lib
     with pytest.raises(_lib.DdmpError):
         ops.gemm_nt(torch.randn(8, 8), torch.randn(8, 8))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_spmm_forms_are_bit_stable_beside_panel_gemm(dtype):
+    """Two-stream iterations run the gather of one net beside the other net's row-panel GEMMs on the same CUs.  A version of
+    the lean SpMM kernel that kept (quad count, dinv[row]) in ONE 64-bit LDS word returned zeros in the low lane of the packed
+    FMA that broadcast its high half -- only beside the f16x3 panel GEMM, 30-60 % of launches.  Every form
+    of the gather has to reproduce its own result bit for bit while that GEMM runs on a second stream."""
+    from dual_dmp_amd import ops, synth
+    from dual_dmp_amd.mesh import Mesh
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    v, f = synth.open_grid(20, 15)
+    m = Mesh(vs=v, faces=f)
+    e = torch.tensor(m.edges.T, dtype=torch.long)
+    graphs = ((torch.cat([e, e[[1, 0]]], 1).to(dev), len(v)), (torch.from_numpy(m.f_edges).to(dev), len(f)))
+    side = torch.cuda.Stream()
+    A = torch.randn(20000, 256, device=dev)
+    W = torch.randn(256, 256, device=dev) / 16.0
+    H = torch.empty(20000, 256, device=dev)
+    C = 256
+    for idx, n in graphs:
+        g = ops.graph_for(idx, n)
+        X = torch.randn(n, C, device=dev).to(dt)
+        Yp = torch.randn(n, C, device=dev).to(dt)
+        sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        bn4 = torch.rand(4, C, device=dev) + 0.5
+        c10 = torch.rand(2, C, device=dev) * 0.1
+        bias = torch.randn(C, device=dev)
+        forms = {"plain": lambda Y, s: ops.spmm(g, X, out=Y, bias=bias), "prologue": lambda Y, s: ops.spmm(g, X, out=Y, pro=(sc, sh)),
+                 "bnred": lambda Y, s: ops.spmm_bnred(g, X, Y, Yp, bn4, s), "bnbwd": lambda Y, s: ops.spmm_bnbwd(g, X, Yp, bn4, c10, Y)}
+        for name, fn in forms.items():
+            Y0 = torch.empty(n, C, device=dev, dtype=dt)
+            s0 = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            fn(Y0, s0)
+            torch.cuda.synchronize()
+            for it in range(120):
+                with torch.cuda.stream(side):
+                    ops.gemm_nt(A, W, out=H)
+                Y1 = torch.empty(n, C, device=dev, dtype=dt)
+                s1 = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+                fn(Y1, s1)
+                torch.cuda.synchronize()
+                assert torch.equal(Y0, Y1) and torch.equal(s0, s1), (name, n, it)
