@@ -1,6 +1,6 @@
 """Eager / hipGraph / two-stream / two-stream hipGraph iterations of one small mesh, N times over in one process: losses, outputs
 and parameters must be bit-identical across all of them (tests/test_gpu_path.py::test_graph_replay_is_bit_identical_to_eager runs it
-once; this is the stress form that found a 5 % flake).  usage: replay_stress.py [repetitions]"""
+once; this is the stress form that found a 5 % flake).  usage: replay_stress.py [repetitions] [f32|bf16]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dual_dmp_amd import synth
@@ -13,13 +13,14 @@ v, f = synth.permute_vertices(v, f, 4)
 gt, noisy, smooth = synth.make_triplet(v, f)
 data = dataset_from_meshes(noisy, smooth); data.to(dev)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+DT = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else torch.float32
 modes = (False, True, "overlap", "overlap+graph")
 ref = None
 fails = 0
 for rep in range(N):
     for graph in modes:
         torch.manual_seed(5)
-        posnet, normnet = PosNet(dev), NormalNet(dev)
+        posnet, normnet = PosNet(dev, dtype=DT), NormalNet(dev, dtype=DT)
         tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=4,
                           use_graph=graph in (True, "overlap+graph"), overlap=str(graph).startswith("overlap"))
         losses = [tr.step().item() for _ in range(9)]
