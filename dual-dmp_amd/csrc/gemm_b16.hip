@@ -529,12 +529,37 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_dma_kernel(
         goff[i] = min(tm0 + col, M - 8);                         // so each wave still issues exactly four copies per stage
         zoff[i] = min(tk0 + col, K - 8);
     }
-    auto copy = [&](int r0, __bf16* buf) {                       // stage rows r0 .. r0 + 31 -> buf (G image, then Z image)
+    // running source pointers: the stages are copied in increasing row order, kBK rows apart (no 64-bit multiply per copy);
+    // rows in [r_end, n_rows) are the next split's -- valid memory, their G rows are zeroed in LDS by the ragged stage --
+    // and only rows past the matrix end are clamped
+    const bf16_t* gsrc[2];
+    const bf16_t* zsrc[2];
+    int next_r0 = r_begin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gsrc[i] = G + (int64_t)(r_begin + crow[i]) * ldg + goff[i];
+        zsrc[i] = Z + (int64_t)(r_begin + crow[i]) * ldz + zoff[i];
+    }
+    auto copy = [&](int, __bf16* buf) {                          // stage rows next_r0 .. next_r0 + 31 -> buf (G image, then Z image)
+        if (next_r0 + kBK <= n_rows) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (gon[i]) dma16(gsrc[i], buf + (8 * i + wave) * 512);
+                if (zon[i]) dma16(zsrc[i], buf + kStage + (8 * i + wave) * 512);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t back = (int64_t)(next_r0 + crow[i]) - min(next_r0 + crow[i], n_rows - 1);
+                if (gon[i]) dma16(gsrc[i] - back * ldg, buf + (8 * i + wave) * 512);
+                if (zon[i]) dma16(zsrc[i] - back * ldz, buf + kStage + (8 * i + wave) * 512);
+            }
+        }
+        next_r0 += kBK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int64_t row = min(r0 + crow[i], r_end - 1);
-            if (gon[i]) dma16(G + row * ldg + goff[i], buf + (8 * i + wave) * 512);
-            if (zon[i]) dma16(Z + row * ldz + zoff[i], buf + kStage + (8 * i + wave) * 512);
+            gsrc[i] += (int64_t)kBK * ldg;
+            zsrc[i] += (int64_t)kBK * ldz;
         }
     };
 
