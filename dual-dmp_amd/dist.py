@@ -641,6 +641,7 @@ class DistributedTrainer:
         import os
         if losses is None:
             losses = "replicated" if loss_engine is not None else os.environ.get("DDMP_DIST_LOSSES", "sharded")
+        # (with losses="sharded", ``loss_engine`` may be a factory (local_mesh, shard) -> engine: the CPU tests' stand-in)
         if losses not in ("sharded", "replicated"):
             raise ValueError("losses must be 'sharded' or 'replicated', got %r" % (losses,))
         self.losses = losses
@@ -661,7 +662,8 @@ class DistributedTrainer:
             sh = _Shard()
             sh.own_v, sh.own_f = torch.from_numpy(ls.own_v).to(device), torch.from_numpy(ls.own_f).to(device)
             sh.V_glob, sh.F_glob, sh.all_reduce = ls.V_glob, ls.F_glob, backend.all_reduce_sum
-            loss_engine = LossEngine(ls.mesh, device, bnfloop=bnfloop, k=k, shard=sh)
+            sh.rank_shard = ls
+            loss_engine = loss_engine(ls.mesh, sh) if callable(loss_engine) else LossEngine(ls.mesh, device, bnfloop=bnfloop, k=k, shard=sh)
         elif loss_engine is None:
             from .loss import LossEngine
             loss_engine = LossEngine(n_mesh, device, bnfloop=bnfloop, k=k)

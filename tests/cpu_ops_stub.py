@@ -228,3 +228,83 @@ class OracleLossEngine:
         buf = torch.zeros(12, dtype=torch.float64)
         buf[5] = total.detach()
         return buf, gp, gn
+
+
+class ShardedOracleLossEngine:
+    """CPU stand-in of loss.LossEngine(shard=...) for the multi-rank tests: one rank's share of the five losses on its
+    sub-mesh (dist.LossShard), written with torch ops after the oracle's formulas (oracle/ddmp_oracle.py: pos_rec_loss,
+    mesh_laplacian_loss, norm_rec_loss, fn_bnf_loss, pos_norm_loss).  VALUES: partial sums over the rows the rank owns,
+    all-reduced (sigma_c before the filter passes, S1..S5 before the scalars).  GRADIENTS: every local term with the global
+    coefficients; exact on the owned rows because the closure holds everything those reach (the copy of the mesh's last
+    face at the end of the local faces only serves the f2f == -1 gathers)."""
+
+    def __init__(self, local_mesh, shard, k, bnfloop):
+        self.m, self.sh, self.k, self.loop = local_mesh, shard, [float(x) for x in k], int(bnfloop)
+        m = local_mesh
+        self.real_v = torch.from_numpy(np.asarray(m.vs, dtype=np.float64))
+        self.real_f = torch.from_numpy(np.asarray(m.fn, dtype=np.float64))
+        self.faces = torch.from_numpy(np.asarray(m.faces, dtype=np.int64))
+        self.f2f = torch.from_numpy(np.asarray(m.f2f, dtype=np.int64))
+        e = torch.from_numpy(np.asarray(m.edges, dtype=np.int64))
+        nv = len(m.vs)
+        self.src = torch.cat([e[:, 0], e[:, 1]])
+        self.dst = torch.cat([e[:, 1], e[:, 0]])
+        self.deg = torch.bincount(self.src, minlength=nv).clamp(min=1).to(torch.float64)
+        self.own_v = shard.own_v.to(torch.float64)
+        self.own_f = shard.own_f.to(torch.float64)
+        self.real_rows = torch.ones(len(m.faces), dtype=torch.float64)
+        self.real_rows[-1] = 0.0                                   # the trailing copy of the mesh's last face
+
+    def _sums(self, p, n, sigma_c):
+        d1 = ((self.real_v - p) ** 2).sum(1)
+        lap = torch.zeros_like(p).index_add_(0, self.src, p[self.dst]) / self.deg[:, None].to(p.dtype)
+        d2 = ((p - lap) ** 2).sum(1)
+        d3 = (n - self.real_f).abs().sum(1)
+        pd = p.detach()
+        p0, p1, p2 = pd[self.faces[:, 0]], pd[self.faces[:, 1]], pd[self.faces[:, 2]]
+        fc = (p0 + p1 + p2) / 3.0
+        cr = torch.linalg.cross(p1 - p0, p2 - p0, dim=1)
+        fa = 0.5 * torch.sqrt((cr * cr).sum(1) + 1.0e-12)
+        mask = (self.f2f != -1).to(n.dtype)
+        fcd = ((fc[self.f2f] - fc[:, None, :]) ** 2).sum(2)
+        dist_sum = (torch.sqrt(fcd + 1.0e-12).sum(1).double() * self.own_f).sum()
+        d4 = None
+        if sigma_c is not None:
+            nb_fa = fa[self.f2f] * mask
+            cur = n
+            for _ in range(self.loop):
+                nb = cur[self.f2f]
+                fnd = ((nb - cur[:, None, :]) ** 2).sum(2)
+                w = (torch.exp(-fcd / (2 * sigma_c ** 2)) * torch.exp(-fnd / (2 * 0.3 ** 2)) * nb_fa)[:, :, None]
+                acc = (w * nb).sum(1)
+                cur = acc / (torch.sqrt((acc * acc).sum(1)[:, None] + 1.0e-12) + 1.0e-12)
+            d4 = (cur - n).abs().sum(1)
+        pf = p[self.faces]
+        pc = pf - (pf.sum(1) / 3.0)[:, None, :]
+        d5 = (pc * n[:, None, :]).sum(2).abs().sum(1)
+        return d1, d2, d3, d4, d5, dist_sum
+
+    def forward_backward(self, pos, norm, gate4):
+        sh, k = self.sh, self.k
+        V, F = float(sh.V_glob), float(sh.F_glob)
+        with torch.enable_grad():
+            p = pos.detach().clone().requires_grad_(True)
+            n = norm.detach().clone().requires_grad_(True)
+            sig = self._sums(p, n, None)[5].reshape(1).clone()
+            sh.all_reduce(sig)
+            sigma_c = (sig[0] / (3.0 * F)).to(n.dtype)
+            d1, d2, d3, d4, d5, _ = self._sums(p, n, sigma_c)
+            S = torch.stack([(d1.double() * self.own_v).sum(), (d2.double() * self.own_v).sum(), (d3.double() * self.own_f).sum(),
+                             (d4.double() * self.own_f).sum(), (d5.double() * self.own_f).sum()]).detach().clone()
+            sh.all_reduce(S)
+            l1, l2 = torch.sqrt(S[0] / V + 1.0e-6), torch.sqrt(S[1] / V + 1.0e-12)
+            l3, l4, l5 = S[2] / F, S[3] / F * gate4, S[4] / V
+            total = k[0] * l1 + k[1] * l2 + k[2] * l3 + k[3] * l4 + k[4] * l5
+            # d total / d S_i, then every local term with that coefficient
+            c = [k[0] / (2.0 * V * l1), k[1] / (2.0 * V * l2), k[2] / F, k[3] * gate4 / F, k[4] / V]
+            G = (c[0] * d1.double().sum() + c[1] * d2.double().sum() + c[2] * (d3.double() * self.real_rows).sum()
+                 + c[3] * (d4.double() * self.real_rows).sum() + c[4] * (d5.double() * self.real_rows).sum())
+            gp, gn = torch.autograd.grad(G, [p, n])
+        buf = torch.zeros(12, dtype=torch.float64)
+        buf[5] = total.detach()
+        return buf, gp, gn

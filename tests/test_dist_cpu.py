@@ -161,7 +161,7 @@ def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P):
     assert bad <= 1e-3 * tot, (bad, tot)
 
 
-def _gloo_worker(rank, world, port, q, interleave="0"):
+def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated"):
     try:
         os.environ["DDMP_DIST_INTERLEAVE"] = interleave
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -178,7 +178,10 @@ def _gloo_worker(rank, world, port, q, interleave="0"):
         oracle = load_oracle()
         noisy, smooth, data = _mesh("ico2")
         results = {}
-        _rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, oracle, results)
+        if losses == "sharded":
+            _sharded_rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, results, epoch0=0)
+        else:
+            _rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, oracle, results)
         out, pa, na = results[rank]
         q.put((rank, [(l, p.numpy(), n.numpy()) for l, p, n in out], pa.numpy(), na.numpy()))
         dist.barrier()
@@ -188,11 +191,12 @@ def _gloo_worker(rank, world, port, q, interleave="0"):
         raise
 
 
-@pytest.mark.parametrize("interleave", ["0", "1"])
-def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave):
+@pytest.mark.parametrize("interleave,losses", [("0", "replicated"), ("1", "replicated"), ("0", "sharded"), ("1", "sharded")])
+def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave, losses):
     """The real torch.distributed code path (all_to_all_single halo exchange, all_reduce of BN sums / gradients /
     pos+norm) with world_size 2 over gloo; both the blocking default and the interleaved async_op=True form
-    (DDMP_DIST_INTERLEAVE=1)."""
+    (DDMP_DIST_INTERLEAVE=1); both loss modes -- "sharded" is what a multi-GPU run uses by default (ghost exchanges of
+    pos / norm + partial-sum all-reduces)."""
     import torch.multiprocessing as mp
     import cpu_ops_stub as stub
     _patch(monkeypatch.setattr, stub)
@@ -200,8 +204,8 @@ def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave):
     ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 200) + 200 * int(interleave)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, interleave)) for r in range(2)]
+    port = 29600 + (os.getpid() % 200) + 200 * int(interleave) + (400 if losses == "sharded" else 0)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, interleave, losses)) for r in range(2)]
     [p.start() for p in procs]
     got = {}
     for _ in range(2):
@@ -266,3 +270,72 @@ def test_loss_shard_closure_and_exchange(P, kind, loop):
                 assert q.send_counts[r] == cnt
                 assert np.array_equal(q.owned[q.send_idx[s0:s0 + cnt]], mine.halo[off:off + cnt])
                 off += cnt
+
+
+def _sharded_rank_run(rank, P, backend, noisy, smooth, data, steps, stub, results, nets=None, loop=1, epoch0=100):
+    from dual_dmp_amd import dist as D
+    k = (3.0, 4.0, 4.0, 4.0, 1.0)
+    tr = D.make_distributed_trainer(noisy, smooth, data, torch.device("cpu"), rank, P, backend=backend, ops_mod=stub, nets=nets,
+                                    bnfloop=loop, losses="sharded",
+                                    loss_engine=lambda local_mesh, sh: stub.ShardedOracleLossEngine(local_mesh, sh, k, loop))
+    tr.epoch = epoch0                                                    # 100: BNF gate open, the filter's ghost rings matter
+    out = []
+    for _ in range(steps):
+        loss = float(tr.step())
+        out.append((loss, tr.pos.clone(), tr.norm.clone()))
+    results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone())
+
+
+@pytest.mark.parametrize("P,kind,loop", [(2, "ico2", 1), (3, "grid", 2)])
+def test_threaded_ranks_with_sharded_losses_match_unpartitioned(monkeypatch, oracle, P, kind, loop):
+    """The default multi-GPU path -- losses sharded by recomputation on a ghost closure (dist.LossShard, two ghost exchanges,
+    two partial-sum all-reduces) -- against the unpartitioned run with the oracle's whole-mesh losses.  Compute is the torch
+    stand-in; what is tested is the closure, the local tables, the exchange plans and the trainer's plumbing."""
+    import cpu_ops_stub as stub
+    from dual_dmp_amd import dist as D
+    from dual_dmp_amd import engine, trainer, networks
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    _patch(monkeypatch.setattr, stub)
+    noisy, smooth, data = _mesh(kind)
+    # unpartitioned reference with the gate open and the same loop count
+    torch.manual_seed(0)
+    posnet, normnet = PosNet("cpu"), NormalNet("cpu")
+    tr = FusedTrainer.__new__(FusedTrainer)
+    tr.posnet, tr.normnet, tr.dataset, tr.device = posnet, normnet, data, torch.device("cpu")
+    tr.pos_lr = tr.norm_lr = 0.01
+    tr.grad_crip, tr.betas, tr.eps, tr.bnf_start_epoch = 0.8, (0.9, 0.999), 1e-8, 100
+    tr.loss_engine = stub.OracleLossEngine(oracle, noisy, (3.0, 4.0, 4.0, 4.0, 1.0), loop)
+    tr.peng, tr.neng = posnet._get_engine(data), normnet._get_engine(data)
+    tr.m = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+    tr.v = [torch.zeros_like(posnet.arena.data), torch.zeros_like(normnet.arena.data)]
+    tr.sumsq = torch.zeros(1, dtype=torch.float64)
+    tr.epoch, tr.t, tr.use_graph, tr.overlap = 100, 0, False, False
+    ref = []
+    for _ in range(2):
+        ref.append((float(tr.step()), tr.pos.clone(), tr.norm.clone()))
+    nets = []
+    for _ in range(P):
+        torch.manual_seed(0)
+        nets.append((PosNet("cpu"), NormalNet("cpu")))
+    comms = D.ThreadComm.make(P)
+    results, errs = {}, []
+
+    def work(r):
+        try:
+            _sharded_rank_run(r, P, comms[r], noisy, smooth, data, 2, stub, results, nets=nets[r], loop=loop)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            comms[r].s.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    for r in range(P):
+        out = results[r][0]
+        (l0, p0, n0), (l1, p1, n1) = ref[0], out[0]
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (r, l0, l1)
+        assert float((p0 - p1).abs().max()) < 2e-5 and float((n0 - n1).abs().max()) < 2e-5
+        assert abs(ref[1][0] - out[1][0]) <= 1e-2 * abs(ref[1][0]), (r, ref[1][0], out[1][0])
+        assert torch.equal(results[r][1], results[0][1]) and torch.equal(results[r][2], results[0][2])
