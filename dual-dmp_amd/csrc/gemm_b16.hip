@@ -638,28 +638,41 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_dma_kernel(
     }
 }
 
-// dW = sum over splits of the partial panels (float64 accumulation); 4 splits x 4 elements in flight per thread
+// dW = sum over splits of the partial panels: see reduce_splits_kernel (gemm.hip) -- 64 float4 columns per workgroup, the
+// splits dealt to its four waves, float64 partial sums combined through LDS in wave order
 __global__ __launch_bounds__(256) void reduce_splits_b16_kernel(const float* __restrict__ part, int64_t split_stride,
                                                                 int n_splits, float* __restrict__ dW, int64_t lddw, int M,
                                                                 int K) {
-    const int q = blockIdx.x * 256 + threadIdx.x;                // float4 index (K % 4 == 0)
-    if (q * 4 >= M * K) return;
+    __shared__ double sm[3][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;                        // float4 index (K % 4 == 0)
+    const bool on = q * 4 < M * K;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = 0;
-    for (; i + 3 < n_splits; i += 4) {
-        float4 v[4];
+    if (on) {
+        int i = wave;
+        for (; i + 12 < n_splits; i += 16) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(i + u) * split_stride + 4 * q);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(part + (int64_t)(i + 4 * u) * split_stride + 4 * q);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+        }
+        for (; i < n_splits; i += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)i * split_stride + 4 * q);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
     }
-    for (; i < n_splits; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)i * split_stride + 4 * q);
-        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    if (wave > 0) {
+        sm[wave - 1][lane][0] = s0; sm[wave - 1][lane][1] = s1; sm[wave - 1][lane][2] = s2; sm[wave - 1][lane][3] = s3;
     }
-    const int idx = 4 * q, m = idx / K, k = idx % K;
-    float* o = dW + (int64_t)m * lddw + k;
-    o[0] = (float)s0; o[1] = (float)s1; o[2] = (float)s2; o[3] = (float)s3;
+    __syncthreads();
+    if (wave == 0 && on) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { s0 += sm[w][lane][0]; s1 += sm[w][lane][1]; s2 += sm[w][lane][2]; s3 += sm[w][lane][3]; }
+        const int idx = 4 * q, m = idx / K, k = idx % K;
+        float* o = dW + (int64_t)m * lddw + k;
+        o[0] = (float)s0; o[1] = (float)s1; o[2] = (float)s2; o[3] = (float)s3;
+    }
 }
 
 struct TnPlanB {
@@ -803,7 +816,7 @@ extern "C" int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t*
         hipLaunchKernelGGL((gemm_tn_b16_kernel<false>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
                            (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);
     LAUNCH_TRY();
-    hipLaunchKernelGGL(reduce_splits_b16_kernel, dim3((unsigned)cdiv((int64_t)M * K, 1024)), dim3(256), 0, st, part, sstride,
+    hipLaunchKernelGGL(reduce_splits_b16_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, st, part, sstride,
                        p.n_splits, dW, lddw, M, K);
     LAUNCH_TRY();
     return DDMP_OK;
