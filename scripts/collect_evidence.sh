@@ -22,6 +22,11 @@ python3 scripts/rocpd_summary.py "$DB" --top 60 > $O/${TAG}${SUF}_bench_kernel_s
 FD=$(ls $O/${TAG}${SUF}_pmc_F/*/*results.db $O/${TAG}${SUF}_pmc_F/*results.db 2>/dev/null | head -1)
 WD=$(ls $O/${TAG}${SUF}_pmc_W/*/*results.db $O/${TAG}${SUF}_pmc_W/*results.db 2>/dev/null | head -1)
 python3 scripts/pmc_traffic.py "$FD" "$WD" "bench.py $PROF (4 eager iterations per pass)" $DT 4 > $O/${TAG}${SUF}_pmc_hbm_traffic.json 2>> $O/${TAG}${SUF}_prof.log
+# second bench run with this tree's PMC file in place, so that the line carries roofline.traffic (the first line is kept)
+mkdir -p $R/profiles
+cp $O/${TAG}${SUF}_pmc_hbm_traffic.json $R/profiles/
+mv $O/${TAG}${SUF}_bench_line.json $O/${TAG}${SUF}_bench_line_first_run.json
+python3 bench.py --dtype $DT --steps 20 --warmup 5 --kernel-table $O/${TAG}${SUF}_bench_kernel_table_hip_events.json > $O/${TAG}${SUF}_bench_line.json 2>> $O/${TAG}${SUF}_bench.err
 # keep the merge-back small: the raw databases stay on the box
 rm -rf $O/${TAG}${SUF}_prof $O/${TAG}${SUF}_pmc_F $O/${TAG}${SUF}_pmc_W
 ls -la $O | grep ${TAG}${SUF}
