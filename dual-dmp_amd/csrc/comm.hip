@@ -180,6 +180,7 @@ extern "C" int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* p, void
     const int es = dtype == DDMP_BF16 ? 2 : 4;
     ARG_TRY(ld >= C && (C * es) % 16 == 0 && (ld * es) % 16 == 0 && b16_aligned(T) && (n_sums == 0 || sums));
     if (ws_bytes < ddmp_halo_pack_bytes(p, C, dtype) || (p->n_send > 0 && (!pack_ws || !b16_aligned(pack_ws)))) return DDMP_EWORKSPACE;
+    if (p->n_cols > p->n_rows && ld != C) return DDMP_EINVAL;    // halo rows are received in place: contiguous rows only
     hipStream_t st = (hipStream_t)stream;
     const size_t row_bytes = (size_t)C * es;
     if (p->n_send > 0) {
@@ -191,20 +192,23 @@ extern "C" int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* p, void
     if (comm->world == 1 && n_sums == 0) return DDMP_OK;
     Rccl& R = rccl();
     NCCL_TRY(R.GroupStart());
+    // Inside the group nothing returns early: a return between GroupStart and GroupEnd would leave every later RCCL call
+    // of this thread nested in a group that never launches (a hang instead of an error).  The first failure is kept, the
+    // remaining calls are skipped, the group is always closed.
+    int err = 0;
     int64_t soff = 0, roff = 0;
-    for (int r = 0; r < p->world; ++r) {
+    for (int r = 0; r < p->world && !err; ++r) {
         const int64_t ns = p->send_counts[r], nr = p->recv_counts[r];
-        if (ns > 0 && ld == C) NCCL_TRY(R.Send((const char*)pack_ws + soff * row_bytes, (size_t)ns * row_bytes, kNcclInt8, r, comm->comm, st));
-        else if (ns > 0) NCCL_TRY(R.Send((const char*)pack_ws + soff * row_bytes, (size_t)ns * row_bytes, kNcclInt8, r, comm->comm, st));
-        if (nr > 0) {
-            if (ld != C) return DDMP_EINVAL;                     // halo rows are received in place: contiguous rows only
-            NCCL_TRY(R.Recv((char*)T + (size_t)(p->n_rows + roff) * row_bytes, (size_t)nr * row_bytes, kNcclInt8, r, comm->comm, st));
-        }
+        if (ns > 0) err = R.Send((const char*)pack_ws + soff * row_bytes, (size_t)ns * row_bytes, kNcclInt8, r, comm->comm, st);
+        if (nr > 0 && !err)
+            err = R.Recv((char*)T + (size_t)(p->n_rows + roff) * row_bytes, (size_t)nr * row_bytes, kNcclInt8, r, comm->comm, st);
         soff += ns;
         roff += nr;
     }
-    if (n_sums > 0) NCCL_TRY(R.AllReduce(sums, sums, (size_t)n_sums, kNcclFloat64, kNcclSum, comm->comm, st));
-    NCCL_TRY(R.GroupEnd());
+    if (n_sums > 0 && !err) err = R.AllReduce(sums, sums, (size_t)n_sums, kNcclFloat64, kNcclSum, comm->comm, st);
+    const int end = R.GroupEnd();
+    if (err) return 1000 + err;
+    if (end) return 1000 + end;
     return DDMP_OK;
 }
 

@@ -267,8 +267,11 @@ __global__ __launch_bounds__(512) void gemm_rows_b16_kernel(
             cnt = 0;
             epilogue(cur_t);
             zero_acc();
+            // the counted wait below assumes EVERY lane issued all NST stores: only true for a full tile of a full-width
+            // panel (the stores are predicated per lane; a wave whose lanes all fail issues none).  Otherwise the
+            // smaller count is used, which only over-waits.
+            stored = MD == MP && (cur_t + 1) * BMR <= n_rows;
             cur_t += gridDim.x;
-            stored = true;
         }
     };
     b_copy(0);

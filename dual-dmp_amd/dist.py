@@ -318,6 +318,21 @@ class NativeComm:
         torch.cuda.synchronize(self.device)
         self.dist.barrier()
 
+    def close(self):
+        """Destroy the halo plans and the communicator (idempotent; also run by the finalizer)."""
+        plans, self._plans = self._plans, {}
+        for h, _ in plans.values():
+            self.L.ddmp_halo_plan_destroy(h)
+        h, self.h = self.h, None
+        if h is not None:
+            self.L.ddmp_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def _lib_check(st, what):
     from . import _lib
@@ -617,6 +632,16 @@ class DistributedTrainer:
         """``losses``: "sharded" (every rank evaluates the loss terms of its own rows on a ghost closure; two small
         all-reduces of partial sums; default on the GPU) or "replicated" (one all-gather of pos | norm, every rank
         runs the whole-mesh losses; what a caller-supplied ``loss_engine`` implies).  Env: DDMP_DIST_LOSSES."""
+        import contextlib
+        # graphs and engines allocate on the CURRENT device (ddmp_graph_create): enter the device context here too
+        # (the CPU tests run this class on a torch stand-in of ops: nothing to enter there)
+        ctx = ops.on_device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
+        with ctx:
+            self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
+                       eps, bnf_start_epoch, ops_mod, loss_engine, losses)
+
+    def _init(self, posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas, eps,
+              bnf_start_epoch, ops_mod, loss_engine, losses):
         from .engine import GcnEngine, POS_WIDTHS, NORM_WIDTHS
         self.ops = ops_mod or ops
         self.backend, self.device = backend, device
@@ -690,7 +715,8 @@ class DistributedTrainer:
         """pos | norm of the whole mesh on every rank: ONE all-gather of the owned rows (padded to the largest shard),
         scattered to their global places.  COLLECTIVE: every rank has to call it (gather_pos / gather_norm / .pos /
         .norm do) at the same point; cached until the next step."""
-        if self._full_epoch == self.epoch and self._full is not None:
+        key = (getattr(self.peng, "n_forward", 0), getattr(self.neng, "n_forward", 0))    # any forward (step, net(data),
+        if self._full_epoch == key and self._full is not None:                            # eval) invalidates the cache
             return self._full
         sd, dev = self.sd, self.device
         if self._full is None:
@@ -704,7 +730,7 @@ class DistributedTrainer:
         self._gather_send[nv:nv + nf].copy_(norm_loc)
         self.backend.all_gather_rows(self._gather_recv, self._gather_send)
         self._full.index_copy_(0, self._gather_dst, self._gather_recv)
-        self._full_epoch = self.epoch
+        self._full_epoch = key
         return self._full
 
     def gather_pos(self):
@@ -715,6 +741,8 @@ class DistributedTrainer:
         with self.ops.on_device(self.device):
             return self._assemble_full()[self.sd.V: self.sd.V + self.sd.F]
 
+    # Convenience spellings of the two methods above (FusedTrainer has .pos / .norm attributes).  They are COLLECTIVES like
+    # the methods: every rank has to read them at the same point -- `if rank == 0: tr.pos` deadlocks; prefer the methods.
     pos = property(gather_pos)
     norm = property(gather_norm)
 
@@ -733,7 +761,10 @@ class DistributedTrainer:
         return lossbuf, dpos[:nv], dnorm[:nf]
 
     def check_scales(self) -> int:
-        return self.peng.check_scales() + self.neng.check_scales()
+        from .trainer import nonfinite_check
+        healed = self.peng.check_scales() + self.neng.check_scales()
+        nonfinite_check((("PosNet", self.posnet), ("NormalNet", self.normnet)))
+        return healed
 
     @torch.no_grad()
     def step(self):

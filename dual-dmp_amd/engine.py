@@ -307,6 +307,7 @@ class GcnEngine:
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
         (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        self.n_forward = getattr(self, "n_forward", 0) + 1        # (dist: cache key of the all-gathered outputs)
         self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
         X, pro = self.x0, None
         halo_started = False

@@ -18,6 +18,15 @@ from . import ops
 from .loss import LossEngine
 
 
+def nonfinite_check(nets):
+    """Raise OverflowError when a parameter or gradient arena holds a NaN / inf (see FusedTrainer.check_scales)."""
+    for name, net in nets:
+        for what, t in (("parameters", net.arena.data), ("gradients", getattr(net, "_grad_arena", None))):
+            if t is not None and not bool(torch.isfinite(t).all()):
+                raise OverflowError("non-finite %s in %s: NaN or inf in the activations / gradients of the last "
+                                    "iterations" % (what, name))
+
+
 class FusedTrainer:
     def __init__(self, posnet, normnet, dataset, n_mesh, pos_lr=0.01, norm_lr=0.01, k=(3.0, 4.0, 4.0, 4.0, 1.0),
                  grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8, bnf_start_epoch=100, use_graph=False,
@@ -28,6 +37,12 @@ class FusedTrainer:
 
         ``overlap``: PosNet runs on a second HIP stream beside NormalNet (forward, then backward + its Adam
         update); the two nets only meet in the losses.  Same kernels, same results."""
+        with ops.on_device(posnet.device):       # graphs and engines allocate on the CURRENT device (ddmp_graph_create)
+            self._init(posnet, normnet, dataset, n_mesh, pos_lr, norm_lr, k, grad_crip, bnfloop, betas, eps,
+                       bnf_start_epoch, use_graph, overlap)
+
+    def _init(self, posnet, normnet, dataset, n_mesh, pos_lr, norm_lr, k, grad_crip, bnfloop, betas, eps,
+              bnf_start_epoch, use_graph, overlap):
         self.posnet, self.normnet = posnet, normnet
         self.dataset = dataset
         dev = posnet.device
@@ -121,8 +136,15 @@ class FusedTrainer:
     def check_scales(self) -> int:
         """f16 split GEMM modes: number of GEMM operands that outgrew their scale since the last call -- each was redone
         on the device with the measured scale before anything consumed it (GcnEngine.check_scales); raises
-        OverflowError for non-finite operands.  Syncs."""
-        return self.peng.check_scales() + self.neng.check_scales()
+        OverflowError for non-finite operands.  Syncs.
+
+        The scale slots record the operands' maxima with ``fmaxf``, which drops NaN: an inf operand raises through the
+        slots, a NaN operand does not.  NaN activations or activation gradients reach every weight gradient of their layer
+        and, through Adam, the parameters; so the parameter and gradient arenas are tested for finiteness here as well
+        (two reductions over 0.75 M floats each, at the cadence of this call: every 10 epochs in the CLI)."""
+        healed = self.peng.check_scales() + self.neng.check_scales()
+        nonfinite_check((("PosNet", self.posnet), ("NormalNet", self.normnet)))
+        return healed
 
     def step(self):
         with ops.on_device(self.device):

@@ -79,6 +79,58 @@ def test_create_dataset_from_directory(tmp_path, oracle):
     assert datamaker.create_dataset(d)[0]["gt_mesh"] is None
 
 
+def _clean_obj(tmp_path, name="bunny"):
+    """An arbitrary clean OBJ a user would hold: not unit-edge, not centred."""
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.mesh import Mesh
+    v, f = synth.icosphere(2)
+    d = tmp_path / "datasets" / name
+    d.mkdir(parents=True)
+    path = str(d / "scan_clean.obj")
+    Mesh(vs=v * 37.0 + np.array([5.0, -2.0, 11.0]), faces=f).save(path)
+    return str(d), path
+
+
+def test_preprocess_from_one_clean_obj(tmp_path, capsys):
+    """`python -m dual_dmp_amd.preprocess -i <clean.obj> --level 0.2` = preprocess/noisemaker.py:12-80: the directory it
+    leaves behind is what main.py -i reads (util/datamaker.py:26-35)."""
+    from dual_dmp_amd import preprocess, datamaker, synth
+    from dual_dmp_amd.mesh import Mesh
+    d, path = _clean_obj(tmp_path)
+    out = preprocess.main(["-i", path, "--level", "0.2", "--step", "30"])
+    txt = capsys.readouterr().out
+    assert "level       : 0.2" in txt and "[Finished] Vertices: 162, faces: 320, mad:" in txt
+    assert out == d and not os.path.exists(path) and os.path.exists(os.path.join(d, "original", "scan_clean.obj"))
+    g, n, s = (Mesh(os.path.join(d, "bunny_%s.obj" % k)) for k in ("gt", "noise", "smooth"))
+    assert abs(synth.mean_edge_length(g.vs, g.edges) - 1.0) < 1e-6                   # noisemaker.py:32-36
+    lo, hi = g.vs.min(0), g.vs.max(0)
+    assert np.abs(lo + hi).max() < 1e-5                                               # bbox centre at the origin
+    np.random.seed(314)                                                               # noisemaker.py:38-42
+    noise = np.random.normal(loc=0, scale=0.2, size=(len(g.vs), 1))
+    assert np.allclose(n.vs, g.vs + g.vn * noise, atol=1e-6)
+    assert np.allclose(s.vs, synth.laplacian_smooth(n.vs, n.vv_ptr, n.vv_idx, steps=30), atol=1e-6)
+    mesh_dic, ds = datamaker.create_dataset(d)
+    assert mesh_dic["mesh_name"] == "bunny" and mesh_dic["gt_mesh"] is not None
+    assert ds.z1.shape == (162, 16) and ds.z2.shape == (320, 7)
+
+
+def test_preprocess_directory_with_a_noisy_scan(tmp_path):
+    """`-i <dir>` = preprocess/preprocess.py:42-79: *_noise.obj (no ground truth) -> *_smooth.obj, unit mean edge."""
+    from dual_dmp_amd import preprocess, datamaker, synth
+    from dual_dmp_amd.mesh import Mesh
+    v, f = synth.open_grid(9, 7)
+    d = tmp_path / "datasets" / "scan"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    Mesh(vs=v * 12.0 + rng.normal(scale=0.05, size=v.shape), faces=f).save(str(d / "scan_noise.obj"))
+    preprocess.main(["-i", str(d), "--step", "10"])
+    n, s = Mesh(str(d / "scan_noise.obj")), Mesh(str(d / "scan_smooth.obj"))
+    assert abs(synth.mean_edge_length(n.vs, n.edges) - 1.0) < 1e-6
+    assert np.array_equal(n.faces, s.faces) and not np.allclose(n.vs, s.vs)
+    mesh_dic, ds = datamaker.create_dataset(str(d))
+    assert mesh_dic["gt_mesh"] is None and ds.x_pos.shape == (len(v), 3)
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under dual-dmp_amd/ may reference it."""
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dual-dmp_amd")

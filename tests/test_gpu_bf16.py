@@ -161,6 +161,28 @@ def test_gemm_nt_bf16(dev, n, K, M):
         assert relerr(y, z @ wq.t()) < 4e-3
 
 
+@pytest.mark.parametrize("n,K,M", [(70000, 64, 16), (70000, 128, 40), (70000, 256, 48), (70001, 512, 200), (33000, 64, 24)])
+def test_gemm_nt_bf16_partial_width_panels(dev, n, K, M):
+    """Output widths below the padded panel width (M < 32 NJ WC): whole waves issue no epilogue stores, so the counted
+    vmcnt wait behind an epilogue must not assume them (round-2 advisor finding; a miscount leaves global->LDS copies of
+    the next stage in flight at the barrier -- timing dependent, hence the repeats on a many-tile input)."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    ab, a = rb(torch.randn(n, K))
+    w = torch.randn(M, K) / K ** 0.5
+    wq = w.to(BF).double()
+    ref = a @ wq.t()
+    atol = 3e-6 * float((a.abs() @ wq.abs().t()).max())
+    ad, wd = ab.to(dev), w.to(dev)
+    first = None
+    for rep in range(6):
+        y = ops.gemm_nt(ad, wd)
+        nbad, worst = close_bf16(y, ref, atol)
+        assert nbad == 0, (rep, worst)
+        first = y if first is None else first
+        assert torch.equal(y, first), rep
+
+
 @pytest.mark.parametrize("n,M,K", [(1000, 64, 32), (3000, 512, 512), (2049, 512, 256), (2500, 256, 512), (900, 32, 64),
                                     (1300, 128, 256), (130, 256, 256)])
 def test_gemm_nn_bf16(dev, n, M, K):

@@ -505,6 +505,23 @@ def test_cli_runs_like_the_reference(dev, tmp_path, monkeypatch, capsys):
     assert np.array_equal(o.faces, noisy.faces) and np.allclose(o.vs, tr.pos.cpu().numpy(), atol=1e-6)
 
 
+def test_main_trains_on_the_preprocess_output(dev, tmp_path, monkeypatch, capsys):
+    """One clean OBJ -> `python -m dual_dmp_amd.preprocess -i x.obj --level 0.2` -> `main.py -i <dir>`."""
+    from dual_dmp_amd import synth, cli, preprocess
+    from dual_dmp_amd.mesh import Mesh
+    v, f = synth.icosphere(2)
+    d = tmp_path / "datasets" / "bunny"
+    d.mkdir(parents=True)
+    Mesh(vs=v * 20.0 + 3.0, faces=f).save(str(d / "clean.obj"))
+    preprocess.main(["-i", str(d / "clean.obj"), "--level", "0.2"])
+    monkeypatch.chdir(tmp_path)
+    tr = cli.run(["-i", str(d), "--iter", "20", "--seed", "0"], real=False)
+    out = capsys.readouterr().out
+    assert "initial_mad:" in out and "final_mad:" in out and tr.epoch == 20
+    init, final = (float(out.split(k)[1].split()[0]) for k in ("initial_mad:", "final_mad:"))
+    assert final < init                                              # 20 iterations already denoise the sphere
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_vertex_updating_matches_reference_golden(dev, golden_dir, name):
     """util/models.py:31-44 (the reference's per-vertex Python loop) vs the two-kernel sweep."""
