@@ -53,7 +53,11 @@ def parse_args(argv=None):
     ap.add_argument("--overlap", type=int, default=1, help="1: PosNet on a second stream beside NormalNet")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the iteration as one hipGraph (single-GPU path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-faces", type=int, default=250000)
+    ap.add_argument("--cpu-sample-faces", type=int, default=0,
+                    help="faces of the CPU-baseline sample; 0 = the bench size when the host has >= 128 GB, else 250,000")
+    ap.add_argument("--bf16-extra", type=int, default=1,
+                    help="1: the default f32 run also measures the bf16-feature mode (BASELINE configs[1] arithmetic) on the same "
+                         "mesh after the f32 timed region and reports it as the \"bf16\" object of the JSON line")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--extras", type=int, default=1,
@@ -117,16 +121,30 @@ def _oracle_setup(oracle, faces):
     return lambda ep: oracle.train_step(pn, nn_, op, on, odata, noisy, args, ep), noisy
 
 
+def host_mem_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemTotal:"):
+                return int(ln.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(sample_faces, target_faces, iters=3):
     """Oracle (PyG-shaped PyTorch CPU restatement of main.py:88-110) timed on this host: 1 warm-up + `iters` timed
-    iterations at `sample_faces` (default 250,000 faces, SURVEY.md §8d's fall-back size: 1M faces needs ~75 GB and
-    minutes per iteration), reported linearly extrapolated to the bench size (the step is O(faces)).  The thread count is
-    calibrated first on a 20k-face probe and confirmed at the sample size between the two fastest candidates (PyTorch's
-    all-cores default thrashes on a many-core host: 256 threads measured 40x slower than 16 on this workload)."""
+    iterations at `sample_faces`.  sample_faces = 0 (default) picks the bench size itself (1,000,000 faces, ~75 GB RSS) when
+    the host has >= 128 GB of memory, and SURVEY.md §8d's fall-back of 250,000 faces (linearly extrapolated: the step is
+    O(faces)) otherwise.  The thread count is calibrated first on a 20k-face probe and confirmed at 100k faces between the
+    two fastest candidates (PyTorch's all-cores default thrashes on a many-core host: 256 threads measured 40x slower than
+    16 on this workload).  Time budget: a warm-up iteration slower than 80 s / 150 s cuts the timed iterations to 2 / 1."""
     import resource
     import torch
     oracle = load_oracle()
     ncpu = os.cpu_count() or 1
+    mem = host_mem_gb()
+    if sample_faces <= 0:
+        sample_faces = target_faces if mem >= 128.0 else min(target_faces, 250000)
     cands = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, 8)})
     step, _ = _oracle_setup(oracle, 20000)
     probe = {}
@@ -137,30 +155,37 @@ def cpu_baseline(sample_faces, target_faces, iters=3):
         step(2)
         probe[t] = time.perf_counter() - t0
     ranked = sorted(cands, key=lambda t: probe[t])
-    step, noisy = _oracle_setup(oracle, sample_faces)
-    F = len(noisy.faces)
+    step, _ = _oracle_setup(oracle, min(100000, sample_faces))
     torch.set_num_threads(ranked[0])
-    step(1)                                            # warm-up (allocator, index caches)
-    best, per_thread = ranked[0], {}
-    for t in ranked[:2]:                               # confirm at the sample size: one timed iteration each
+    step(1)
+    per_thread = {}
+    for t in ranked[:2]:                               # confirm at 100k faces: one timed iteration each
         torch.set_num_threads(t)
         t0 = time.perf_counter()
         step(2)
         per_thread[t] = time.perf_counter() - t0
     best = min(per_thread, key=per_thread.get)
+    del step
+    step, noisy = _oracle_setup(oracle, sample_faces)
+    F = len(noisy.faces)
     torch.set_num_threads(best)
     t0 = time.perf_counter()
-    for ep in range(3, 3 + iters):
+    step(1)                                            # warm-up (allocator, index caches)
+    warm = time.perf_counter() - t0
+    iters = iters if warm <= 80.0 else min(iters, 2) if warm <= 150.0 else 1
+    t0 = time.perf_counter()
+    for ep in range(2, 2 + iters):
         step(ep)
     dt = (time.perf_counter() - t0) / iters
     rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    extra = "" if F == target_faces else "; value = linear extrapolation to %d faces (host memory %.0f GB < 128 GB)" % (target_faces, mem)
     return {
         "value": (1.0 / dt) * F / target_faces, "unit": "iters/s", "cores": best, "kind": "port",
         "sample": "oracle train_step (PyTorch CPU, PyG-shaped index_select*w+index_add per layer, gcn_norm per call), %d faces / "
-                  "%d verts, %d threads (calibrated: 20k-face probe %s s/iter, at the sample size %s s/iter; %d-core host), 1 warm-up + "
-                  "%d timed iters: %.2f s/iter = %.4f iters/s at that size, peak RSS %.1f GB; value = linear extrapolation to %d faces"
+                  "%d verts, %d threads (calibrated: 20k-face probe %s s/iter, at 100k faces %s s/iter; %d-core host, %.0f GB), "
+                  "1 warm-up (%.1f s) + %d timed iters: %.2f s/iter = %.5f iters/s at that size, peak RSS %.1f GB%s"
                   % (F, len(noisy.vs), best, {t: round(v, 2) for t, v in probe.items()}, {t: round(v, 2) for t, v in per_thread.items()},
-                     ncpu, iters, dt, 1.0 / dt, rss_gb, target_faces),
+                     ncpu, mem, warm, iters, dt, 1.0 / dt, rss_gb, extra),
     }
 
 
@@ -303,7 +328,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")           # (single-process DDMP_FORCE_DIST runs have no launcher)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    def make_trainer(noisy, smooth, data):
+    def make_trainer(noisy, smooth, data, fdt=fdt):
         torch.manual_seed(0)
         if multi:
             from dual_dmp_amd.dist import make_distributed_trainer
@@ -381,9 +406,10 @@ def main():
         out["gate_open_note"] = "epochs > %d: k4 * fn_bnf_loss takes part in the backward (bnfloop=%d)" % (tr.bnf_start_epoch, args.bnfloop)
 
     # ---- profiled pass (separate from the timed region): HIP events around every launch
-    roof = roof_gather = None
-    table = {}
-    if args.profile_steps > 0:
+    def profiled_pass(tr, dtype_name, out):
+        """-> (roofline of the dominant family, roofline of the gather, per-kernel table); family times into `out`."""
+        roof = roof_gather = None
+        table = {}
         if hasattr(tr, "use_graph"):
             tr.use_graph = False             # per-launch events need the eager path
             tr.overlap = False
@@ -410,11 +436,11 @@ def main():
             if gem["ms"] > 0:
                 cand["gemm"] = gem
             dom = max(cand.items(), key=lambda kv: kv[1]["ms"])
-            roof = roofline_obj(dom[0], dom[1], args.dtype)
+            roof = roofline_obj(dom[0], dom[1], dtype_name)
             if dom[0] == "gemm":
                 roof["forms_ms_per_step"] = {k_: round(f_["ms"], 3) for k_, f_ in fam.items() if k_.startswith("gemm")}
             if "spmm" in fam:
-                roof_gather = roofline_obj("spmm", fam["spmm"], args.dtype)
+                roof_gather = roofline_obj("spmm", fam["spmm"], dtype_name)
             for (name, key), a in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 ms = a["ms"] / args.profile_steps
                 table["%s%s" % (name, list(key) if isinstance(key, tuple) else [key])] = {
@@ -426,10 +452,44 @@ def main():
             out["kernel_ms_sum"] = round(sum(v["ms"] for v in fam.values()), 3)
             out["kernel_ms_note"] = ("profiled pass: eager, ONE stream (%.2f ms per step wall); the timed step replays one hipGraph "
                                      "with PosNet on a second stream, so the families overlap there" % eager_ms)
+        return roof, roof_gather, table
+
+    roof = roof_gather = None
+    table = {}
+    if args.profile_steps > 0:
+        roof, roof_gather, table = profiled_pass(tr, args.dtype, out)
+
+    # ---- BASELINE.json configs[1]'s arithmetic (bf16 features) on the same mesh, driver-observed: the default f32 run measures
+    # it here, after the f32 timed region, with the same warm-up / step counts (its own barrier-bracketed timed region)
+    bf16 = None
+    if args.bf16_extra and args.dtype == "f32" and not multi:
+        del tr
+        torch.cuda.empty_cache()
+        trb = make_trainer(noisy, smooth, data, torch.bfloat16)
+        for _ in range(args.warmup):
+            trb.step().item()
+        ms_b, loss_b = timed_steps(trb, args.steps, sync)
+        from dual_dmp_amd.loss import mad as mad_fn
+        from dual_dmp_amd.mesh import Mesh as MeshT
+        ob = MeshT.__new__(MeshT)
+        ob.vs, ob.faces = trb.pos.cpu().numpy().astype(np.float64), noisy.faces
+        MeshT.compute_face_normals(ob)
+        bf16 = {"ms_per_step": round(ms_b, 3), "iters_per_s": round(1e3 / ms_b, 4), "steps": args.steps, "warmup": args.warmup,
+                "dtype": "bf16", "loss": round(float(loss_b), 6),
+                "mad_deg": {"after_%d_iters" % (args.warmup + args.steps): round(float(mad_fn(ob.fn, gt.fn)), 4)},
+                "arithmetic": "bf16 activations / activation gradients in HBM, one bf16 MFMA product per step, f32 accumulate, "
+                              "f32 parameters, f64 BatchNorm statistics (same mesh, weights and step counts as the f32 line)"}
+        if args.profile_steps > 0:
+            ob_ = {}
+            rb, rgb, _ = profiled_pass(trb, "bf16", ob_)
+            bf16.update({"roofline": rb, "roofline_gather": rgb, "kernel_ms_per_step": ob_.get("kernel_ms_per_step")})
+        del trb
+        torch.cuda.empty_cache()
+        tr = None
 
     # ---- the same step on a randomly numbered mesh (worst-case input locality; the engine relabels along a Morton curve)
     if args.extras and not multi and args.order == "native":
-        del tr
+        tr = None
         torch.cuda.empty_cache()
         gt2, noisy2, smooth2, data2 = build_case(args.faces, "random")
         tr2 = make_trainer(noisy2, smooth2, data2)
@@ -454,7 +514,7 @@ def main():
         copy_gbs = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
         torch.cuda.empty_cache()
-        for r_ in (roof, roof_gather):
+        for r_ in (roof, roof_gather) + ((bf16.get("roofline"), bf16.get("roofline_gather")) if bf16 else ()):
             if isinstance(r_, dict) and r_.get("bound") == "hbm":
                 r_["device_copy_GBs"] = round(copy_gbs, 1)
                 r_["frac_of_device_copy"] = round(r_["achieved"] / copy_gbs, 4)
@@ -483,7 +543,7 @@ def main():
                        "setup_s": round(setup_s, 1), "hipgraph_replay": bool(args.graph) and not multi,
                        "two_streams": bool(args.overlap) and not multi},
             "loss": round(float(loss), 6),
-            "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_gather": roof_gather, "cpu_baseline": cpu, "bf16": bf16,
             "gemm_scale_overflow": scale_overflow, "gemm_scale_healed": healed,
         }
         line.update(out)

@@ -267,6 +267,72 @@ def test_f16x3_operand_scaling(dev, f16x3, scale):
     assert float(ops.gemm_nt(z, wg).abs().max()) == 0.0
 
 
+def _f16x3_elementwise_bound(a, w, target):
+    """Per-element error bound of the f16x3 product sum_k a_k w_k (float64 tensors [n,K], [M,K]) from the scheme itself
+    (csrc/gemm_f16s.inc): an operand x is scaled by the power of two s that puts max|x| in [2^(target-1), 2^target) and kept
+    as h1 + h2 (two f16 terms: 22 bits, but never finer than the f16 subnormal step 2^-24 -- rounding error <= 2^-25 / s
+    in the operand's own units), the product h2.h2' (<= 2^-22 |a||w|) is dropped, accumulation is float32:
+        |err| <= sum_k ( |a_k| ew_k + |w_k| ea_k + ea_k ew_k + 2^-22 |a_k||w_k| ) + 2^-23 sqrt(K) sum_k |a_k||w_k|
+        e x_k  = max(2^-23 |x_k|, 2^-25 / s_x)
+    (the last term: float32 accumulation, random-walk estimate; the caller applies a factor 2 of safety)."""
+    def eps(x):
+        amax = float(x.abs().max())
+        e = np.floor(np.log2(amax)) + 1                    # amax in [2^(e-1), 2^e)
+        s = 2.0 ** (target - e)
+        return torch.maximum(x.abs() * 2.0 ** -23, torch.full_like(x, 2.0 ** -25 / s))
+    ea, ew = eps(a), eps(w)
+    aa, ww = a.abs(), w.abs()
+    K = a.shape[1]
+    return aa @ ew.t() + ea @ ww.t() + ea @ ew.t() + (2.0 ** -22 + 2.0 ** -23 * K ** 0.5) * (aa @ ww.t())
+
+
+def test_f16x3_per_row_and_per_column_error(dev, f16x3):
+    """The f16x3 split is fixed-point relative to the operand's GLOBAL maximum, so rel-L2 over the whole result says
+    nothing about quiet rows / columns (round-2 verdict).  Here the rows of A span 1e-6 .. 1 of its maximum and the
+    rows of W (= output columns) span 1e-4 .. 1: every output ELEMENT must sit inside the bound that follows from the
+    scheme (two f16 terms of the scaled operand, dropped h2.h2, float32 accumulation), with the exact pre-pass scale
+    (target 2^15) and with a one-iteration-old scale slot (target 2^10); and every ROW and every COLUMN must be
+    float32-class in its own norm down to 2^-13 of the maximum (1e-5), degrading no faster than the bound says below."""
+    from dual_dmp_amd import ops
+    n, K, M = 40000, 256, 512
+    torch.manual_seed(9)
+    rs = 10.0 ** (-6.0 * torch.rand(n, 1, dtype=torch.float64))      # row scales, log-uniform in [1e-6, 1]
+    rs[0] = 1.0
+    cs = 10.0 ** (-4.0 * torch.rand(M, 1, dtype=torch.float64))
+    cs[0] = 1.0
+    a = (torch.randn(n, K, dtype=torch.float64) * rs).float().double()
+    w = (torch.randn(M, K, dtype=torch.float64) / K ** 0.5 * cs).float().double()
+    ref = a @ w.t()
+    ag, wg = a.float().to(dev), w.float().to(dev)
+    slots = torch.zeros(1, 4, device=dev)
+    for target, stale in ((15, False), (10, True)):
+        if stale:
+            ops.gemm_next_scales(slots[0], None, prime=True)
+            ops.gemm_nt(ag, wg)
+            ops.gemm_scales_roll(slots)
+            ops.gemm_next_scales(slots[0], None)
+        y = ops.gemm_nt(ag, wg).double().cpu()
+        err = (y - ref).abs()
+        bound = 2.0 * _f16x3_elementwise_bound(a, w, target) + 1e-300
+        worst = float((err / bound).max())
+        assert worst <= 1.0, (target, worst)
+        row_rel = (err.norm(dim=1) / ref.norm(dim=1)).numpy()
+        col_rel = (err.norm(dim=0) / ref.norm(dim=0)).numpy()
+        loud_rows = (rs[:, 0] >= (1e-5 if not stale else 1e-3)).numpy()
+        assert row_rel[loud_rows].max() < 4e-6, (target, row_rel[loud_rows].max())
+        assert col_rel.max() < 4e-6, (target, col_rel.max())          # columns mix loud and quiet rows of A: never quiet
+        # the quietest rows (1e-6 of the maximum): what the fixed-point floor leaves -- still ~5 digits with the exact scale
+        assert row_rel.max() < (1e-3 if not stale else 4e-2), (target, row_rel.max())
+    # the wgrad form (both operands activations, reduction over the rows): per output element against the same model
+    g = (torch.randn(n, 256, dtype=torch.float64) * rs * 1e-3).float().double()
+    dw = ops.gemm_tn(g.float().to(dev), ag).double().cpu()
+    refw = g.t() @ a
+    errw = (dw - refw).abs()
+    boundw = 2.0 * _f16x3_elementwise_bound(g.t().contiguous(), a.t().contiguous(), 15) + 1e-300
+    assert float((errw / boundw).max()) <= 1.0, float((errw / boundw).max())
+    assert float(errw.norm() / refw.norm()) < 3e-6
+
+
 def test_f16x3_scale_slots(dev, f16x3):
     """The training-loop protocol: persistent slots, primed once, then each call uses the maximum recorded by the
     previous iteration's kernels (ddmp_gemm_scales_roll).  Growth within the head-room (x 64) is exact business as

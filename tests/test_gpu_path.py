@@ -112,7 +112,8 @@ def _case(dev, which="ico3"):
     from dual_dmp_amd.datamaker import dataset_from_meshes
     v, f = {"ico3": lambda: synth.icosphere(3), "grid": lambda: synth.open_grid(12, 9),
             "cad33": lambda: synth.cube_cad(33),         # 13,068 faces: the fandisk stand-in (README.md:57 of the reference)
-            "grid24": lambda: synth.open_grid(24, 17)}[which]()
+            "grid24": lambda: synth.open_grid(24, 17),
+            "torus144k": lambda: synth.torus(380, 190)}[which]()   # 144,400 faces / 72,200 verts: every bench route is on
     v, f = synth.permute_vertices(v, f, 3)
     gt, noisy, smooth = synth.make_triplet(v, f)
     return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
@@ -302,7 +303,20 @@ def test_main4real_defaults_teacher_forced_over_50_iterations(dev, oracle):
     _teacher_forced(dev, oracle, "grid24", CAD_K, 5, 0, 50, (1, 10, 25, 50))
 
 
-def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at):
+def test_bench_routes_teacher_forced_beside_the_oracle_at_144k(dev, oracle):
+    """The routes bench.py times -- f16x3 row-panel GEMMs (>= 20-30k rows), BatchNorm statistics from the GEMM epilogue,
+    BatchNorm backward rebuilt on the dgrad / wgrad operand loads and on the SpMM gather, backward reductions from the SpMM
+    epilogue (>= 64k rows), hipGraph replay aside -- are all switched OFF by their row thresholds on the 13k-face meshes
+    of the other oracle comparisons.  Here the same teacher-forced check of main.py:88-110 runs at 144,400 faces /
+    72,200 vertices (both nets above every threshold, asserted), default GEMM mode, against oracle.train_step in float32
+    and the oracle's float64 gradients: iterations 1 and 2, same bounds as test_training_step_teacher_forced."""
+    from dual_dmp_amd import ops
+    if os.environ.get("DDMP_GEMM_PANEL") == "0" or ops.get_gemm_mode() != 13:
+        pytest.skip("not the default GEMM configuration")
+    _teacher_forced(dev, oracle, "torus144k", DEFAULT_K, 1, 0, 2, (1, 2), expect_fused=True)
+
+
+def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect_fused=False):
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
     gt, noisy, smooth, data = _case(dev, which)
@@ -315,6 +329,12 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at):
     on = torch.optim.Adam(rn.parameters(), lr=args.norm_lr)
     posnet, normnet = PosNet(dev), NormalNet(dev)
     tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=bnfloop, k=k)
+    if expect_fused:
+        from dual_dmp_amd import ops
+        for eng in (tr.peng, tr.neng):
+            assert eng.n_rows >= 65536
+            assert sum(eng.fuse_bnbwd) >= 4 and sum(eng.fuse_gather_bwd) >= 3, (eng.fuse_bnbwd, eng.fuse_gather_bwd)
+            assert ops.gemm_bnbwd_supported(512, 256, eng.n_rows) and ops.get_gemm_mode() == 13
     for it in range(1, iters + 1):
         if it in check_at:
             for which, (net, ref, opt) in enumerate(((posnet, rp, op), (normnet, rn, on))):
