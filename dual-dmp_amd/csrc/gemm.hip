@@ -369,6 +369,7 @@ TnPlan tn_plan(int64_t n_rows, int M, int K) {
 #include "gemm_bf16x.inc"
 #include "gemm_ws.inc"
 #include "gemm_panel.inc"
+#include "gemm_rr.inc"
 
 }  // namespace
 
@@ -466,6 +467,16 @@ static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const v
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
 }
+// DDMP_GEMM_RR=0 keeps the row-panel kernel for the wide f16x3 GEMMs (A/B comparisons); DDMP_RR_MIN_ROWS: threshold
+static bool rr_enabled() {
+    static int e = -1;
+    if (e < 0) {
+        const char* v = getenv("DDMP_GEMM_RR");
+        e = (v && atoi(v) == 0) ? 0 : 1;
+    }
+    return e == 1;
+}
+static const int64_t kRRMinRows = env_rows("DDMP_RR_MIN_ROWS", 20000);
 // f16 split mode (gemm_f16s.inc): 0 | 13; operand scale slots of the NEXT ddmp_gemm_* call on this host thread
 static int gemm_f16();
 struct ScaleCtx {
@@ -515,11 +526,30 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
         hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
                            transpose ? KD : MD, transpose ? MD : KD, wscale);
+        const bool rr = rr_enabled() && PM != 2 && KD % 32 == 0 && KD >= 64 && KD <= kMaxProK && n_rows >= kRRMinRows &&
+                        (int64_t)n_rows * lda * 4 < ((int64_t)1 << 32);      // (32-bit lane offsets)
         hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
-                           (_Float16*)planes, (const float*)wscale);
+                           (_Float16*)planes, (const float*)wscale, rr ? 1 : 0);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
         const int target = prime ? kF16TargetExact : kF16TargetStale;
         const void* Bh = planes;
+        if (rr) {
+            // row-register kernel (gemm_rr.inc): 128-row tiles x 256-column halves, two workgroups per CU
+            const int n_halves = MP / kRRCols;
+            const int tiles = (int)ddmp::cdiv(n_rows, kRRRows);
+            int slots = std::min(tiles, 2 * device_cus() / n_halves);
+            slots = std::max(8, slots / 8 * 8);
+            dim3 rgrid((unsigned)(slots * n_halves)), rblock(256);
+            for (int heal = 0; heal <= (prime ? 0 : 1); ++heal)
+                hipLaunchKernelGGL((gemm_rr_kernel<PM>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP, Y, ldy,
+                                   n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, slot, (const float*)wscale,
+                                   target, heal);
+            if (stats && sums) {
+                const size_t pbytes = ((size_t)tiles * 2 * 2 * MP * sizeof(double) + 255) / 256 * 256;
+                fpartials_reduce(stats, tiles * 2, MP, MD, (double*)((char*)stats + pbytes), sums, st);
+            }
+            return;
+        }
 #define DDMP_PANEL_H(WR_, WC_, AR_, HEAL_)                                                                        \
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, AR_, PM, 4>), grid, block, 0, st, A, lda, A2, lda2, Bh, Y, ldy,   \
                        n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, slot, (const float*)wscale, \
