@@ -526,10 +526,11 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
         hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
                            transpose ? KD : MD, transpose ? MD : KD, wscale);
-        const bool rr = rr_enabled() && PM != 2 && KD % 32 == 0 && KD >= 64 && KD <= kMaxProK && n_rows >= kRRMinRows &&
-                        (int64_t)n_rows * lda * 4 < ((int64_t)1 << 32);      // (32-bit lane offsets)
+        const bool rr = rr_enabled() && KD >= 64 && KD <= kMaxProK && n_rows >= kRRMinRows &&
+                        (int64_t)n_rows * lda * 4 < ((int64_t)1 << 32) &&                 // (32-bit lane offsets)
+                        (PM != 2 || (int64_t)n_rows * lda2 * 4 < ((int64_t)1 << 32));
         hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
-                           (_Float16*)planes, (const float*)wscale, rr ? 1 : 0);
+                           (_Float16*)planes, (const float*)wscale);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
         const int target = prime ? kF16TargetExact : kF16TargetStale;
         const void* Bh = planes;
@@ -540,10 +541,16 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
             int slots = std::min(tiles, 2 * device_cus() / n_halves);
             slots = std::max(8, slots / 8 * 8);
             dim3 rgrid((unsigned)(slots * n_halves)), rblock(256);
-            for (int heal = 0; heal <= (prime ? 0 : 1); ++heal)
-                hipLaunchKernelGGL((gemm_rr_kernel<PM>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP, Y, ldy,
-                                   n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, slot, (const float*)wscale,
-                                   target, heal);
+            for (int heal = 0; heal <= (prime ? 0 : 1); ++heal) {
+                if (PM != 2 && stats)
+                    hipLaunchKernelGGL((gemm_rr_kernel<PM == 2 ? 0 : PM, true, 3>), rgrid, rblock, 0, st, A, lda, A2, lda2,
+                                       (const _Float16*)Bh, MP, Y, ldy, n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles,
+                                       stats, slot, (const float*)wscale, target, heal);
+                else
+                    hipLaunchKernelGGL((gemm_rr_kernel<PM, false, PM == 2 ? 2 : 3>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP,
+                                       Y, ldy, n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, slot,
+                                       (const float*)wscale, target, heal);
+            }
             if (stats && sums) {
                 const size_t pbytes = ((size_t)tiles * 2 * 2 * MP * sizeof(double) + 255) / 256 * 256;
                 fpartials_reduce(stats, tiles * 2, MP, MD, (double*)((char*)stats + pbytes), sums, st);
