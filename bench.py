@@ -283,6 +283,42 @@ def roofline_obj(name, f, dtype):
             "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
 
 
+def gather_ceilings(dev, sizes, dtype):
+    """What the gather kernel reaches on a PERFECTLY LOCAL graph with the same number of CSR entries per row as the mesh
+    graphs (a ring: row i gathers rows i-k..i+k, so every gathered row but one was fetched by the previous row and the HBM
+    traffic is exactly the algorithmic bytes): the on-chip ceiling of this kernel for that fan-in -- each gathered row is a
+    separate trip through the L1 whether it hits or not --, measured in this run at C = 512.  No numbering
+    of a mesh can do better; the distance between it and the device-copy rate is the price of the fan-in itself.
+    sizes: {entries_per_row: n_rows}.  -> {entries_per_row: GB/s algorithmic}"""
+    import torch
+    from dual_dmp_amd import ops
+    out = {}
+    C = 512
+    for entries, n in sorted(sizes.items()):
+        k = (entries - 1) // 2                       # neighbours on each side (+ the self loop the graph adds)
+        offs = [d for d in range(-k, k + 1) if d] + ([k + 1] if (entries - 1) % 2 else [])
+        i = torch.arange(n)
+        src = torch.cat([(i + d)[max(0, -d): n - max(0, d)] for d in offs])       # row i gathers row i + d
+        dst = torch.cat([i[max(0, -d): n - max(0, d)] for d in offs])
+        g = ops.graph_for(torch.stack([src, dst]).to(dev), n)
+        X = torch.randn(n, C, device=dev).to(dtype)
+        Y = torch.empty_like(X)
+        ops.spmm(g, X, out=Y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.spmm(g, X, out=Y)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 5 * 1e3
+        alg = 2.0 * n * C * X.element_size() + 4.0 * g.nnz + 8.0 * n
+        out[int(round(g.nnz / n))] = round(alg / us / 1e3, 1)
+        del g, X, Y
+    torch.cuda.empty_cache()
+    return out
+
+
 def timed_steps(tr, n, sync):
     sync()
     t0 = time.perf_counter()
@@ -441,6 +477,13 @@ def main():
                 roof["forms_ms_per_step"] = {k_: round(f_["ms"], 3) for k_, f_ in fam.items() if k_.startswith("gemm")}
             if "spmm" in fam:
                 roof_gather = roofline_obj("spmm", fam["spmm"], dtype_name)
+                by_fan = {}                      # CSR entries per row (4: face graph, 7: vertex graph) -> bytes, ms
+                for (name, key), a in summ.items():
+                    if name == "spmm" and isinstance(key, tuple):
+                        e = by_fan.setdefault(int(key[1]), dict(bytes=0.0, ms=0.0))
+                        e["bytes"] += a["bytes"] / args.profile_steps
+                        e["ms"] += a["ms"] / args.profile_steps
+                roof_gather["_by_fan_in"] = by_fan
             for (name, key), a in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 ms = a["ms"] / args.profile_steps
                 table["%s%s" % (name, list(key) if isinstance(key, tuple) else [key])] = {
@@ -518,6 +561,25 @@ def main():
             if isinstance(r_, dict) and r_.get("bound") == "hbm":
                 r_["device_copy_GBs"] = round(copy_gbs, 1)
                 r_["frac_of_device_copy"] = round(r_["achieved"] / copy_gbs, 4)
+        # the gather's on-chip ceiling per fan-in, measured now (see gather_ceilings), and the fraction of it the step's launches reach
+        for r_, dt_ in ((roof_gather, fdt),) + (((bf16.get("roofline_gather"), torch.bfloat16),) if bf16 else ()):
+            if not (isinstance(r_, dict) and r_.get("_by_fan_in")):
+                continue
+            fan = r_.pop("_by_fan_in")
+            sizes = {e: (F if e <= 5 else V) for e in fan}
+            ceil = gather_ceilings(dev, sizes, dt_)
+            t_floor = sum(v["bytes"] / (ceil[e] * 1e9) for e, v in fan.items() if e in ceil) * 1e3      # ms
+            r_["by_fan_in"] = {str(e): {"ms_per_step": round(v["ms"], 3), "achieved_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                        "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "local_graph_ceiling_GBs": ceil.get(e)} for e, v in sorted(fan.items())}
+            r_["ceiling"] = {"what": "the same kernel on perfectly local ring graphs with the same CSR entries per row (4 = face "
+                                     "graph, 7 = vertex graph), C = 512, measured in this run: no numbering of a mesh can beat it",
+                             "GBs_by_entries_per_row": {str(k): v for k, v in ceil.items()},
+                             "ms_per_step_at_ceiling": round(t_floor, 3),
+                             "frac_of_ceiling": round(t_floor / r_["ms_per_step"], 4) if r_["ms_per_step"] else None}
+        for r_ in (roof_gather, bf16.get("roofline_gather") if bf16 else None):
+            if isinstance(r_, dict):
+                r_.pop("_by_fan_in", None)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

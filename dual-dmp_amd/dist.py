@@ -259,8 +259,8 @@ class NativeComm:
     """RCCL through the library's OWN communicator and halo plans (csrc/comm.hip, include/ddmp_hip.h "Communicator +
     halo plan + exchange"): the pack kernel, the grouped ncclSend/ncclRecv that lands halo rows in place and the
     BatchNorm-sum all-reduce are enqueued from C on the caller's stream -- no Python collective objects, capturable.
-    torch.distributed is only the bootstrap channel (the 128-byte unique id) and the barrier.  Opt-in
-    (DDMP_DIST_NATIVE=1): no multi-GPU box exists in the build loop, it has run at world size 1 only."""
+    torch.distributed is only the bootstrap channel (the 128-byte unique id) and the barrier.  Default on the GPU since
+    round 3 (DDMP_DIST_NATIVE=0 opts out); no multi-GPU box exists in the build loop: hardware runs at world size 1 only."""
 
     def __init__(self, device):
         import ctypes
@@ -628,20 +628,25 @@ class DistributedTrainer:
 
     def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
-                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None):
+                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None):
         """``losses``: "sharded" (every rank evaluates the loss terms of its own rows on a ghost closure; two small
         all-reduces of partial sums; default on the GPU) or "replicated" (one all-gather of pos | norm, every rank
-        runs the whole-mesh losses; what a caller-supplied ``loss_engine`` implies).  Env: DDMP_DIST_LOSSES."""
+        runs the whole-mesh losses; what a caller-supplied ``loss_engine`` implies).  Env: DDMP_DIST_LOSSES.
+
+        ``backend_pos``: a SECOND communicator for PosNet.  Given one (make_distributed_trainer creates it for the native
+        RCCL backend), the step runs PosNet on a second HIP stream beside NormalNet -- forward, then backward + gradient
+        all-reduce + Adam update -- exactly like the single-device FusedTrainer(overlap=True); each stream owns its
+        communicator, so the two nets' collectives never share one.  Off: DDMP_DIST_STREAMS=0."""
         import contextlib
         # graphs and engines allocate on the CURRENT device (ddmp_graph_create): enter the device context here too
         # (the CPU tests run this class on a torch stand-in of ops: nothing to enter there)
         ctx = ops.on_device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
         with ctx:
             self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
-                       eps, bnf_start_epoch, ops_mod, loss_engine, losses)
+                       eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
 
     def _init(self, posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas, eps,
-              bnf_start_epoch, ops_mod, loss_engine, losses):
+              bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos):
         from .engine import GcnEngine, POS_WIDTHS, NORM_WIDTHS
         self.ops = ops_mod or ops
         self.backend, self.device = backend, device
@@ -650,8 +655,13 @@ class DistributedTrainer:
         self.sd = sd
         vg = self.ops.Graph.from_csr_host(sd.vplan.rowptr, sd.vplan.col, sd.vplan.dinv, sd.vplan.n_cols)
         fg = self.ops.Graph.from_csr_host(sd.fplan.rowptr, sd.fplan.col, sd.fplan.dinv, sd.fplan.n_cols)
+        import os
+        self.two_streams = (backend_pos is not None and torch.device(device).type == "cuda"
+                            and os.environ.get("DDMP_DIST_STREAMS", "1") != "0")
+        self.backend_pos = backend_pos if self.two_streams else backend
+        self._side = torch.cuda.Stream(device=device) if self.two_streams else None
         self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
-                              comm=GraphComm(backend, sd.vplan, device), n_total=sd.V,
+                              comm=GraphComm(self.backend_pos, sd.vplan, device), n_total=sd.V,
                               dtype=getattr(posnet, "feature_dtype", torch.float32))
         self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
                               comm=GraphComm(backend, sd.fplan, device), n_total=sd.F,
@@ -780,7 +790,13 @@ class DistributedTrainer:
         pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
         # the two nets alternate at their collectives: one net's halo exchange / BatchNorm all-reduce is in flight
         # while the other net's kernels run
-        if self.interleaved:
+        if self.two_streams:
+            self._fork()
+            with torch.cuda.stream(self._side):
+                self.peng.forward(pa, update_running=True)
+            self.neng.forward(na, update_running=True)
+            self._join()
+        elif self.interleaved:
             interleave(self.peng.forward_steps(pa, update_running=True), self.neng.forward_steps(na, update_running=True))
         else:
             self.peng.forward(pa, update_running=True)
@@ -793,30 +809,68 @@ class DistributedTrainer:
             full = self._assemble_full()
             lossbuf, dpos, dnorm = self.loss_engine.forward_backward(full[:V], full[V:V + self.sd.F], gate)
             dpos_loc, dnorm_loc = dpos.index_select(0, self.owned_v), dnorm.index_select(0, self.owned_f)
-        if self.interleaved:
-            interleave(self.peng.backward_steps(pa, pg, dpos_loc), self.neng.backward_steps(na, ng, dnorm_loc))
-        else:
-            self.peng.backward(pa, pg, dpos_loc)
+        if self.two_streams:
+            self._fork()
+            if dpos_loc.is_cuda:
+                dpos_loc.record_stream(self._side)               # (allocated on this stream, read on the other)
+            with torch.cuda.stream(self._side):                  # PosNet: backward, gradient all-reduce, Adam -- beside NormalNet
+                self.peng.backward(pa, pg, dpos_loc)
+                self.posnet._reduce_grads()
+                o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
             self.neng.backward(na, ng, dnorm_loc)
-        self.posnet._reduce_grads()
-        self.normnet._reduce_grads()
+            self.normnet._reduce_grads()
+        else:
+            if self.interleaved:
+                interleave(self.peng.backward_steps(pa, pg, dpos_loc), self.neng.backward_steps(na, ng, dnorm_loc))
+            else:
+                self.peng.backward(pa, pg, dpos_loc)
+                self.neng.backward(na, ng, dnorm_loc)
+            self.posnet._reduce_grads()
+            self.normnet._reduce_grads()
+            o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
         o.grad_sumsq(ng, out=self.sumsq)
-        o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
         o.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
                      clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        if self.two_streams:
+            self._join()
         self.lossbuf = lossbuf
         return lossbuf[5]
+
+    def _fork(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+
+    def _join(self):
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        torch.cuda.current_stream().wait_event(ev)
 
 
 def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnfloop=1, backend=None, nets=None, **kw):
     from .networks import PosNet, NormalNet
+    backend_pos = kw.pop("backend_pos", None)
     if backend is None:
+        # Default on the GPU: the library's own RCCL communicators (csrc/comm.hip: pack + ONE grouped send/recv per layer
+        # with the BatchNorm sums in the same group, enqueued from C on the caller's stream) -- two of them, so that PosNet
+        # runs on a second stream beside NormalNet.  DDMP_DIST_NATIVE=0 (or RCCL not resolvable) falls back to
+        # torch.distributed's process group: blocking collectives on one stream.
         import os
-        native = os.environ.get("DDMP_DIST_NATIVE") == "1" and torch.device(device).type == "cuda"
-        backend = NativeComm(device) if native else TorchDistComm()
+        backend = None
+        if torch.device(device).type == "cuda" and os.environ.get("DDMP_DIST_NATIVE", "1") != "0":
+            try:
+                backend = NativeComm(device)
+                if os.environ.get("DDMP_DIST_STREAMS", "1") != "0":
+                    backend_pos = NativeComm(device)
+            except Exception as e:      # noqa: BLE001  (every rank takes the same branch: RCCL is there for all or none)
+                import warnings
+                warnings.warn("native RCCL backend unavailable (%s): falling back to torch.distributed" % (e,))
+                backend = backend_pos = None
+        if backend is None:
+            backend = TorchDistComm()
     if nets is None:
         torch.manual_seed(0)                   # identical initial parameters on every rank
         nets = (PosNet(device), NormalNet(device))
     posnet, normnet = nets
     sharded = ShardedData(dataset, n_mesh, rank, world)
-    return DistributedTrainer(posnet, normnet, sharded, n_mesh, backend, device, bnfloop=bnfloop, **kw)
+    return DistributedTrainer(posnet, normnet, sharded, n_mesh, backend, device, bnfloop=bnfloop, backend_pos=backend_pos, **kw)

@@ -269,7 +269,7 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
     es = x.element_size()
     # algorithmic bytes: every feature row read once + written once, int32 col ids, rowptr, dinv
     alg = 2.0 * g.n_rows * C * es + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
-    with _timed("spmm", C, alg, 2.0 * g.nnz * C):
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):      # key: width, CSR entries per row
         st = _lib.lib().ddmp_spmm(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
                                   _stream())
     check(st, "ddmp_spmm")
@@ -285,7 +285,7 @@ def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
     L = _lib.lib()
     ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), x.device)
     alg = 3.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
-    with _timed("spmm", C, alg, 2.0 * g.nnz * C):
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
         st = L.ddmp_spmm_bnred(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
     check(st, "ddmp_spmm_bnred")
@@ -305,7 +305,8 @@ def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
     C = dz.shape[1]
     assert dz.shape[0] >= g.n_cols and yb.shape[0] >= g.n_cols and out.shape[0] >= g.n_rows and yb.shape[1] == C
     es = dz.element_size()
-    with _timed("spmm", C, es * (2.0 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows, 2.0 * g.nnz * C):
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), es * (2.0 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows,
+                2.0 * g.nnz * C):
         st = _lib.lib().ddmp_spmm_bnbwd(g.handle, _p(dz), lddz, _p(yb), ldyb, _p(out), ldo, C, _dt(dz), _p(bn4[0]),
                                         _p(bn4[1]), _p(c10[0]), _p(c10[1]), slope, _stream())
     check(st, "ddmp_spmm_bnbwd")

@@ -13,13 +13,17 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("kind,losses,interleave,native", [("ico4", "sharded", "0", "0"), ("grid", "sharded", "1", "0"),
-                                                           ("ico4", "replicated", "1", "0"), ("grid", "sharded", "0", "1")])
-def test_rccl_ranks_match_single_device(kind, losses, interleave, native):
+@pytest.mark.parametrize("kind,losses,interleave,native,streams", [
+    ("ico4", "sharded", "0", "0", "1"), ("grid", "sharded", "1", "0", "1"), ("ico4", "replicated", "1", "0", "1"),
+    # the library's own RCCL communicators (the default backend): PosNet on a second stream with its own communicator, and
+    # the single-stream form
+    ("grid", "sharded", "0", "1", "1"), ("ico4", "replicated", "0", "1", "1"), ("grid", "sharded", "0", "1", "0")])
+def test_rccl_ranks_match_single_device(kind, losses, interleave, native, streams):
     n = min(2, torch.cuda.device_count())                   # counting devices does not initialise the GPU in this process
     assert n >= 1
-    env = dict(os.environ, DDMP_DIST_INTERLEAVE=interleave, DDMP_DIST_NATIVE=native, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + (os.getpid() + hash((kind, losses, interleave, native))) % 300
+    env = dict(os.environ, DDMP_DIST_INTERLEAVE=interleave, DDMP_DIST_NATIVE=native, DDMP_DIST_STREAMS=streams,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() + hash((kind, losses, interleave, native, streams))) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "nccl_worker.py"), kind, losses, "3"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
