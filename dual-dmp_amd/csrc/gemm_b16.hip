@@ -351,11 +351,15 @@ __device__ __forceinline__ int tn_off(int row, int col) {         // element off
     return row * kTT + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31));
 }
 
-template <bool ZPRO>
+// GDUAL: the G operand is the BatchNorm+LeakyReLU backward of (G = dZ, G2 = Yb) rebuilt on the fly and rounded to bf16 --
+// what bn_bwd_apply would have written (coefficients per column of G: ga, gb, gk1, gk0)
+template <bool ZPRO, bool GDUAL = false>
 __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
     const bf16_t* __restrict__ G, int64_t ldg, const bf16_t* __restrict__ Z, int64_t ldz, float* __restrict__ out,
     int64_t ld_out, int64_t split_stride, int n_rows, int M, int K, int rows_per_split, int n_tiles_m, int n_tiles_k,
-    int n_splits, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope) {
+    int n_splits, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
+    const bf16_t* __restrict__ G2 = nullptr, int64_t ldg2 = 0, const float* __restrict__ ga = nullptr,
+    const float* __restrict__ gb = nullptr, const float* __restrict__ gk1 = nullptr, const float* __restrict__ gk0 = nullptr) {
     constexpr int kStage = kBK * kTT;                            // elements of one operand stage
     __shared__ __attribute__((aligned(16))) __bf16 Gs[2][kStage];
     __shared__ __attribute__((aligned(16))) __bf16 Zs[2][kStage];
@@ -382,12 +386,22 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
         ld8f(pscale + zcol, pa);
         ld8f(pshift + zcol, pb);
     }
-    uint4 rg[2][2], rz[2][2];                                    // [slot][pass]
+    float ca[GDUAL ? 8 : 1], cb[GDUAL ? 8 : 1], ck1[GDUAL ? 8 : 1], ck0[GDUAL ? 8 : 1];
+    if constexpr (GDUAL) {
+        if (g_on) {
+            ld8f(ga + gcol, ca);
+            ld8f(gb + gcol, cb);
+            ld8f(gk1 + gcol, ck1);
+            ld8f(gk0 + gcol, ck0);
+        }
+    }
+    uint4 rg[2][2], rz[2][2], rg2[GDUAL ? 2 : 1][2];             // [slot][pass]
     auto load = [&](int sl, int r0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int64_t row = min(r0 + p * 16 + sr, r_end - 1);
             rg[sl][p] = g_on ? ld8b(G + row * ldg + gcol) : make_uint4(0, 0, 0, 0);
+            if constexpr (GDUAL) rg2[sl][p] = g_on ? ld8b(G2 + row * ldg2 + gcol) : make_uint4(0, 0, 0, 0);
             rz[sl][p] = z_on ? ld8b(Z + row * ldz + zcol) : make_uint4(0, 0, 0, 0);
         }
     };
@@ -396,6 +410,15 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
         for (int p = 0; p < 2; ++p) {
             const int r = p * 16 + sr;
             uint4 g = rg[sl][p], z = rz[sl][p];
+            if constexpr (GDUAL) {
+                float x[8], y[8];
+                bf_unpack8(g, x);
+                bf_unpack8(rg2[sl][p], y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)                      // = BwdApplyF (bn.hip), element for element
+                    x[e] = fmaf(ca[e], x[e] * lrelu_grad(fmaf(y[e], ca[e], cb[e]), slope), fmaf(ck1[e], y[e], ck0[e]));
+                g = g_on ? bf_pack8(x) : make_uint4(0, 0, 0, 0);
+            }
             if (r0 + r >= r_end) g = make_uint4(0, 0, 0, 0);     // rows beyond the split contribute nothing
             if (ZPRO) {
                 float f[8];
@@ -678,6 +701,9 @@ __global__ __launch_bounds__(256) void reduce_splits_b16_kernel(const float* __r
     }
 }
 
+#include "fpartials.inc"
+#include "gemm_rr_b16.inc"
+
 struct TnPlanB {
     int n_tiles_m, n_tiles_k, n_splits, rows_per_split;
 };
@@ -723,6 +749,70 @@ void launch_rows(const bf16_t* A, int64_t lda, const __bf16* planes, bf16_t* Y, 
                            (int)n_rows, KD, MD, bias, ps, psh, slope, n_tiles);
 }
 
+// DDMP_GEMM_RR=0 keeps the row-panel kernel (A/B comparisons); DDMP_RR_MIN_ROWS: the row threshold
+bool rr_b16_enabled() {
+    static int e = -1;
+    if (e < 0) {
+        const char* v = getenv("DDMP_GEMM_RR");
+        e = (v && atoi(v) == 0) ? 0 : 1;
+    }
+    return e == 1;
+}
+int64_t rr_b16_min_rows() {
+    static int64_t n = -1;
+    if (n < 0) {
+        const char* v = getenv("DDMP_RR_MIN_ROWS");
+        n = (v && atoll(v) > 0) ? atoll(v) : 20000;
+    }
+    return n;
+}
+bool rr_b16_ok(int64_t n_rows, int KD, int MD, int64_t lda, int64_t lda2) {
+    return rr_b16_enabled() && n_rows >= rr_b16_min_rows() && MD >= 128 && MD <= 512 && MD % 8 == 0 && KD % kBK == 0 && KD >= kBK &&
+           KD <= kMaxK && n_rows * lda * 2 < ((int64_t)1 << 32) && n_rows * lda2 * 2 < ((int64_t)1 << 32);
+}
+size_t rr_b16_stats_bytes(int64_t n_rows) {
+    return (size_t)(cdiv(n_rows, 64) + 8) * 2 * 512 * sizeof(double) + 256 + fpartials_mid_bytes(512);
+}
+
+// row-register kernel (gemm_rr_b16.inc).  BWD: the operand is the BatchNorm backward of (A = dZ, A2 = Yb); stats_ws / sums:
+// BatchNorm statistics of the output from the epilogue
+template <bool BWD>
+int launch_rr_b16(const bf16_t* A, int64_t lda, const bf16_t* A2, int64_t lda2, const float* W, int64_t ldw, int transpose,
+                  bf16_t* Y, int64_t ldy, int64_t n_rows, int KD, int MD, const float* bias, const float* ps, const float* psh,
+                  const float* pc1, const float* pc0, float slope, void* ws, size_t ws_bytes, void* stats_ws,
+                  size_t stats_ws_bytes, double* sums, hipStream_t st) {
+    const int MPW = MD > kRBCols ? 512 : 256;
+    const size_t need = (size_t)KD * MPW * sizeof(uint16_t);
+    if (!ws || ws_bytes < need || !b16_aligned(ws)) return DDMP_EWORKSPACE;
+    if (sums && (!stats_ws || stats_ws_bytes < rr_b16_stats_bytes(n_rows))) return DDMP_EWORKSPACE;
+    __bf16* planes = (__bf16*)ws;
+    hipLaunchKernelGGL(w_planes_b16_kernel, dim3((unsigned)std::min<int64_t>(cdiv((int64_t)KD * MPW, 256), 1024)), dim3(256), 0,
+                       st, W, ldw, MD, KD, transpose, MPW, planes);
+    LAUNCH_TRY();
+    const int n_halves = MPW / kRBCols;
+    const int tiles = (int)cdiv(n_rows, kRBRows);
+    int slots = std::min(tiles, 2 * device_cus_b16() / n_halves);
+    slots = std::max(8, slots / 8 * 8);
+    dim3 grid((unsigned)(slots * n_halves)), block(256);
+    double* stats = (double*)stats_ws;
+#define DDMP_RRB(PM_, ST_, NB_)                                                                                        \
+    hipLaunchKernelGGL((gemm_rr_b16_kernel<PM_, ST_, NB_>), grid, block, 0, st, A, lda, A2, lda2, planes, MPW, Y, ldy,  \
+                       (int)n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats)
+    if (BWD) DDMP_RRB(2, false, 2);
+    else if (sums && ps) DDMP_RRB(1, true, 3);
+    else if (sums) DDMP_RRB(0, true, 3);
+    else if (ps) DDMP_RRB(1, false, 3);
+    else DDMP_RRB(0, false, 3);
+#undef DDMP_RRB
+    LAUNCH_TRY();
+    if (sums) {
+        const size_t pbytes = ((size_t)tiles * 2 * 2 * MPW * sizeof(double) + 255) / 256 * 256;
+        fpartials_reduce(stats, tiles * 2, MPW, MD, (double*)((char*)stats + pbytes), sums, st);
+        LAUNCH_TRY();
+    }
+    return DDMP_OK;
+}
+
 // Y[n, MD] = f(A[n, KD]) . B  with B[k][m] = transpose ? W[k][m] : W[m][k]
 int gemm_rows_b16(const bf16_t* A, int64_t lda, const float* W, int64_t ldw, int transpose, bf16_t* Y, int64_t ldy,
                   int64_t n_rows, int KD, int MD, const float* bias, const float* ps, const float* psh, float slope,
@@ -742,6 +832,11 @@ int gemm_rows_b16(const bf16_t* A, int64_t lda, const float* W, int64_t ldw, int
         return DDMP_OK;
     }
     ARG_TRY(KD % kBK == 0 && (!ps || KD <= kMaxK));
+    // plain products: the row-register kernel where it measured faster than the row-panel kernel (1M-face step, round 3:
+    // K = 512 -> 256 | 512 columns 288 vs 320 us and 261 vs 271 us; shorter contractions lose to its heavier epilogue)
+    if (rr_b16_ok(n_rows, KD, MD, lda, 0) && KD >= 512 && MD > 128)
+        return launch_rr_b16<false>(A, lda, nullptr, 0, W, ldw, transpose, Y, ldy, n_rows, KD, MD, bias, ps, psh, nullptr, nullptr,
+                                    slope, ws, ws_bytes, nullptr, 0, nullptr, st);
     const int MP = planes_mp(MD);
     const size_t need = (size_t)KD * MP * sizeof(uint16_t);
     if (!ws || ws_bytes < need || !b16_aligned(ws)) return DDMP_EWORKSPACE;
@@ -781,6 +876,84 @@ extern "C" int ddmp_gemm_nn_bf16(const uint16_t* A, int64_t lda, const float* W,
     ARG_TRY(ldw >= K);
     return gemm_rows_b16(A, lda, W, ldw, 1, Y, ldy, n_rows, M, K, nullptr, nullptr, nullptr, 0.f, workspace,
                          workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t ddmp_gemm_nt_stats_bf16_workspace_bytes(int64_t n_rows, int M) {
+    if (n_rows <= 0 || M <= 0) return 0;
+    return rr_b16_stats_bytes(n_rows);
+}
+
+// 1 = ddmp_gemm_nt_stats_bf16 takes its statistics from the GEMM epilogue and the two *_bnbwd_bf16 forms exist for this
+// shape (row-register kernel); 0 = the caller runs the separate passes (bn_stats / bn_bwd_apply)
+extern "C" int ddmp_gemm_fused_bf16_supported(int cout, int cin, int64_t n_rows) {
+    // bit 0: ddmp_gemm_nt_stats_bf16 (measured against GEMM + bn_stats at 1M faces: 128|256 -> 256, 256 -> 512: 35-38 us
+    //        per launch faster; 512 -> 512: a tie)
+    // bit 1: the two *_bnbwd_bf16 forms (against bn_bwd_apply + the plain GEMMs: 512 <- 256: -157 us, 256 <- 256: -75 us,
+    //        256 <- 128: -52 us per layer; 512 <- 512: +100 us -- the register-staged wgrad is 316 us slower than the all-DMA
+    //        one it replaces -- so that shape keeps the separate pass)
+    int r = 0;
+    if (rr_b16_ok(n_rows, cin, cout, cin, 0) && cout > 128) r |= 1;
+    if (rr_b16_ok(n_rows, cout, cin, cout, cout) && !(cout >= 512 && cin >= 512)) r |= 2;
+    return r;
+}
+
+extern "C" int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                                       int64_t n_rows, int K, int M, const float* bias, const float* pro_scale,
+                                       const float* pro_shift, float slope, double* sums2, void* workspace,
+                                       size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream) {
+    ARG_TRY(A && W && Y && sums2 && n_rows > 0 && n_rows < INT32_MAX && K > 0 && M > 0 && ldw >= K);
+    ARG_TRY(lda >= K && ldy >= M && lda % 8 == 0 && ldy % 8 == 0 && b16_aligned(A) && b16_aligned(Y));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    if (!rr_b16_ok(n_rows, K, M, lda, 0)) return DDMP_EINVAL;
+    return launch_rr_b16<false>(A, lda, nullptr, 0, W, ldw, 0, Y, ldy, n_rows, K, M, bias, pro_scale, pro_shift, nullptr, nullptr,
+                                slope, workspace, workspace_bytes, stats_ws, stats_ws_bytes, sums2, (hipStream_t)stream);
+}
+
+// out[n, K] = bf16(dY) . W[M, K] with dY = BatchNorm+LeakyReLU backward of (dZ, Yb) rebuilt on the operand load
+extern "C" int ddmp_gemm_nn_bnbwd_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb, const float* W,
+                                       int64_t ldw, uint16_t* out, int64_t ld_out, int64_t n_rows, int M, int K,
+                                       const float* a, const float* b, const float* c1, const float* c0, float slope,
+                                       void* workspace, size_t workspace_bytes, ddmp_stream stream) {
+    ARG_TRY(dZ && Yb && W && out && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0 && ldw >= K);
+    ARG_TRY(lddz >= M && ldyb >= M && ld_out >= K && lddz % 8 == 0 && ldyb % 8 == 0 && ld_out % 8 == 0);
+    ARG_TRY(b16_aligned(dZ) && b16_aligned(Yb) && b16_aligned(out) && b16_aligned(a) && b16_aligned(b) && b16_aligned(c1) && b16_aligned(c0));
+    if (!rr_b16_ok(n_rows, M, K, lddz, ldyb)) return DDMP_EINVAL;
+    return launch_rr_b16<true>(dZ, lddz, Yb, ldyb, W, ldw, 1, out, ld_out, n_rows, M, K, nullptr, a, b, c1, c0, slope, workspace,
+                               workspace_bytes, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+// dW[M, K] = bf16(dY)^T . f(Z) with dY as above
+extern "C" int ddmp_gemm_tn_bnbwd_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb, const uint16_t* Z,
+                                       int64_t ldz, float* dW, int64_t lddw, int64_t n_rows, int M, int K, const float* a,
+                                       const float* b, const float* c1, const float* c0, const float* pro_scale,
+                                       const float* pro_shift, float slope, void* workspace, size_t workspace_bytes,
+                                       ddmp_stream stream) {
+    ARG_TRY(dZ && Yb && Z && dW && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0 && M % 8 == 0 && K % 8 == 0);
+    ARG_TRY(lddz >= M && ldyb >= M && ldz >= K && lddw >= K && lddz % 8 == 0 && ldyb % 8 == 0 && ldz % 8 == 0);
+    ARG_TRY(b16_aligned(dZ) && b16_aligned(Yb) && b16_aligned(Z) && b16_aligned(a) && b16_aligned(b) && b16_aligned(c1) && b16_aligned(c0));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(!pro_scale || (b16_aligned(pro_scale) && b16_aligned(pro_shift)));
+    hipStream_t st = (hipStream_t)stream;
+    const TnPlanB p = tn_plan_b16(n_rows, M, K);
+    const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float);
+    if (!workspace || workspace_bytes < need || !b16_aligned(workspace)) return DDMP_EWORKSPACE;
+    float* part = (float*)workspace;
+    const int64_t sstride = (int64_t)M * K;
+    const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(512);
+    if (pro_scale)
+        hipLaunchKernelGGL((gemm_tn_b16_kernel<true, true>), grid, block, 0, st, dZ, lddz, Z, ldz, part, (int64_t)K, sstride,
+                           (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope,
+                           Yb, ldyb, a, b, c1, c0);
+    else
+        hipLaunchKernelGGL((gemm_tn_b16_kernel<false, true>), grid, block, 0, st, dZ, lddz, Z, ldz, part, (int64_t)K, sstride,
+                           (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope,
+                           Yb, ldyb, a, b, c1, c0);
+    LAUNCH_TRY();
+    hipLaunchKernelGGL(reduce_splits_b16_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, st, part, sstride,
+                       p.n_splits, dW, lddw, M, K);
+    LAUNCH_TRY();
+    return DDMP_OK;
 }
 
 extern "C" size_t ddmp_gemm_tn_bf16_workspace_bytes(int64_t n_rows, int M, int K) {

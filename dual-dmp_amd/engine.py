@@ -198,8 +198,16 @@ class GcnEngine:
         # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
         self.agg_first = [L.cin_p[l] <= L.cout[l] for l in range(12)]
         supported = getattr(ops, "gemm_bnbwd_supported", None)
-        self.fuse_bnbwd = [bool(supported) and dtype == torch.float32 and l > 0 and self.agg_first[l]
-                           and supported(L.cout[l], L.cin_p[l], self.n_rows) for l in range(12)]
+        def _bnbwd_ok(l):
+            if not supported or l == 0 or not self.agg_first[l]:
+                return False
+            if dtype == torch.float32:
+                return supported(L.cout[l], L.cin_p[l], self.n_rows)
+            try:                                                 # bf16 features: row-register kernel (round 3)
+                return supported(L.cout[l], L.cin_p[l], self.n_rows, dtype) and os.environ.get("DDMP_BF16_FUSE", "1") != "0"
+            except TypeError:                                    # (a stand-in of ops without the dtype argument)
+                return False
+        self.fuse_bnbwd = [bool(_bnbwd_ok(l)) for l in range(12)]
         # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
         # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
         # bf16 features: rebuilding dY on the gather reads two rows per CSR entry; measured (scripts/microbench.py spmm

@@ -338,7 +338,27 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
 def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     """gemm_nt that also fills ``sums`` (float64 [2M]) with the column sums of out and out^2 (= bn_stats(out)):
     produced in the row-panel kernel's epilogue where that kernel runs, by a separate pass otherwise."""
-    if a.dtype == torch.bfloat16:                        # bf16 features: the GEMM, then the streaming statistics pass
+    if a.dtype == torch.bfloat16:
+        # bf16 features: statistics from the row-register kernel's epilogue where that kernel runs (round 3), else the
+        # GEMM followed by the streaming statistics pass
+        n = a.shape[0] if n_rows is None else n_rows
+        K, M = a.shape[1], w.shape[0]
+        L = _lib.lib()
+        if L.ddmp_gemm_fused_bf16_supported(int(M), int(K), int(n)) & 1:
+            a, lda = _mat(a, "a")
+            w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
+            if out is None:
+                out = torch.empty((n, M), dtype=a.dtype, device=a.device)
+            out, ldy = _mat(out, "out", a)
+            ps, psh = (None, None) if pro is None else pro
+            nb = (L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)) + 255) // 256 * 256
+            sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, M)
+            ws = Workspace.get(nb + sb, a.device)
+            with _timed("gemm_nt", (K, M), 2.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+                st = L.ddmp_gemm_nt_stats_bf16(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
+                                               _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream())
+            check(st, "ddmp_gemm_nt_stats_bf16")
+            return out
         out = gemm_nt(a, w, out=out, bias=bias, pro=pro, slope=slope, n_rows=n_rows)
         bn_stats(out, sums=sums, n_rows=n_rows)
         return out
@@ -406,7 +426,9 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
 
 def gemm_bnbwd_supported(cout, cin, n_rows, dtype=torch.float32):
     """Do the fused BatchNorm-backward GEMMs exist for a layer cin -> cout over n_rows rows in the current GEMM mode?
-    (float32 features only: the bf16-feature GEMMs take dY as written by bn_bwd_apply.)"""
+    (bf16 features: on the row-register kernel, round 3.)"""
+    if dtype == torch.bfloat16:
+        return bool(_lib.lib().ddmp_gemm_fused_bf16_supported(int(cout), int(cin), int(n_rows)) & 2)
     if dtype != torch.float32:
         return False
     return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin), int(n_rows)))
@@ -436,6 +458,22 @@ def to_bf16(src, dst=None):
 def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
     """out[n,K] = dY[n,M] @ w[M,K] with dY = BatchNorm+LeakyReLU backward of (dz, yb) computed on the operand load
     (what bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
+    if dz.dtype == torch.bfloat16:
+        dz, lddz = _mat(dz, "dz")
+        yb, ldyb = _mat(yb, "yb", dz)
+        w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
+        n = dz.shape[0] if n_rows is None else n_rows
+        M, K = w.shape
+        if out is None:
+            out = torch.empty((n, K), dtype=dz.dtype, device=dz.device)
+        out, ldo = _mat(out, "out", dz)
+        L = _lib.lib()
+        ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(dz)), dz.device)
+        with _timed("gemm_nn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+            st = L.ddmp_gemm_nn_bnbwd_bf16(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                           _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream())
+        check(st, "ddmp_gemm_nn_bnbwd_bf16")
+        return out
     dz, lddz = _mat(dz, "dz")
     yb, ldyb = _mat(yb, "yb")
     w, ldw = _mat(w, "w")
@@ -455,6 +493,23 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
 
 def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=None):
     """out[M,K] = dY^T @ f(z) with dY as in gemm_nn_bnbwd."""
+    if dz.dtype == torch.bfloat16:
+        dz, lddz = _mat(dz, "dz")
+        yb, ldyb = _mat(yb, "yb", dz)
+        z, ldz = _mat(z, "z", dz)
+        n = dz.shape[0] if n_rows is None else n_rows
+        M, K = yb.shape[1], z.shape[1]
+        if out is None:
+            out = torch.empty((M, K), dtype=torch.float32, device=dz.device)
+        out, ldo = _mat(_chk(out, torch.float32, "out"), "out")
+        L = _lib.lib()
+        ws = Workspace.get(L.ddmp_gemm_tn_ws_bytes(n, M, K, _dt(dz)), dz.device)
+        ps, psh = (None, None) if pro is None else pro
+        with _timed("gemm_tn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+            st = L.ddmp_gemm_tn_bnbwd_bf16(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                           _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream())
+        check(st, "ddmp_gemm_tn_bnbwd_bf16")
+        return out
     dz, lddz = _mat(dz, "dz")
     yb, ldyb = _mat(yb, "yb")
     z, ldz = _mat(z, "z")

@@ -343,6 +343,31 @@ size_t ddmp_gemm_tn_bf16_workspace_bytes(int64_t n_rows, int M, int K);
 int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t ldz, float* dW, int64_t lddw,
                       int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift, float slope,
                       void* workspace, size_t workspace_bytes, ddmp_stream stream);
+/* Fused forms on the row-register kernel (csrc/gemm_rr_b16.inc; round 3): the streaming BatchNorm passes of the bf16 step
+ * folded into the GEMMs, as the *_f32 namesakes do for float32 features.
+ *   ddmp_gemm_fused_bf16_supported  bit 0: ddmp_gemm_nt_stats_bf16, bit 1: the two *_bnbwd_bf16 forms exist AND pay for a
+ *                                   layer cin -> cout over n_rows rows (measured thresholds, csrc/gemm_b16.hip)
+ *   ddmp_gemm_nt_stats_bf16         ddmp_gemm_nt_bf16 + sums2[2M] (float64) = column sums of Y and Y^2 as STORED (bf16),
+ *                                   i.e. ddmp_bn_stats_bf16(Y), from the epilogue; stats_ws >= ..._stats_bf16_workspace_bytes
+ *   ddmp_gemm_nn_bnbwd_bf16         out[n,K] = dY . W[M,K], dY = bf16(a dZ lrelu'(a Yb + b) + c1 Yb + c0) rebuilt on the operand
+ *                                   load: what ddmp_bn_bwd_apply_bf16 would have written, never stored
+ *   ddmp_gemm_tn_bnbwd_bf16         dW[M,K] = dY^T . f(Z), the same dY (reference op: GCNConv.lin backward behind
+ *                                   BatchNorm1d + LeakyReLU, util/networks.py:31-44,51-62) */
+int ddmp_gemm_fused_bf16_supported(int cout, int cin, int64_t n_rows);
+size_t ddmp_gemm_nt_stats_bf16_workspace_bytes(int64_t n_rows, int M);
+int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+                            int64_t n_rows, int K, int M, const float* bias, const float* pro_scale,
+                            const float* pro_shift, float slope, double* sums2, void* workspace, size_t workspace_bytes,
+                            void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream);
+int ddmp_gemm_nn_bnbwd_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb, const float* W,
+                            int64_t ldw, uint16_t* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a,
+                            const float* b, const float* c1, const float* c0, float slope, void* workspace,
+                            size_t workspace_bytes, ddmp_stream stream);
+int ddmp_gemm_tn_bnbwd_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb, const uint16_t* Z,
+                            int64_t ldz, float* dW, int64_t lddw, int64_t n_rows, int M, int K, const float* a,
+                            const float* b, const float* c1, const float* c0, const float* pro_scale,
+                            const float* pro_shift, float slope, void* workspace, size_t workspace_bytes,
+                            ddmp_stream stream);
 /* BatchNorm passes: C a power of two in [16, 1024]; workspace = ddmp_colreduce_workspace_bytes(n_rows, C) */
 int ddmp_bn_stats_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, int C, double* sums /*[2C]*/, void* workspace,
                        size_t workspace_bytes, ddmp_stream stream);

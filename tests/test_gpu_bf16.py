@@ -8,6 +8,8 @@ Float32 outputs of bf16 inputs (weight gradients, column sums, head outputs) are
 End to end (12 layers of rounded features) the error is a property of the format, not of a kernel: the measured
 figures are asserted with ~2x head-room and written next to each assert.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -183,8 +185,83 @@ def test_gemm_nt_bf16_partial_width_panels(dev, n, K, M):
         assert torch.equal(y, first), rep
 
 
+RR_SHAPES = [(33000, 256, 512), (70001, 512, 512), (40000, 64, 256), (25000, 128, 200), (21000, 512, 136), (20001, 32, 256),
+             (66000, 256, 256)]
+
+
+@pytest.mark.parametrize("n,K,M", RR_SHAPES)
+def test_gemm_rr_bf16_forward_statistics_and_prologue(dev, n, K, M):
+    """The row-register bf16 kernel (csrc/gemm_rr_b16.inc; >= 20k rows, 64 < M <= 512): plain, with the BatchNorm+LeakyReLU
+    prologue, with bias, and with the BatchNorm statistics of the STORED (bf16) output from the epilogue -- the latter must
+    be the float64 column sums of exactly what was stored (== ddmp_bn_stats_bf16 of the output)."""
+    from dual_dmp_amd import ops
+    if os.environ.get("DDMP_GEMM_RR") == "0":
+        pytest.skip("row-register kernels disabled")
+    from dual_dmp_amd import _lib
+    assert _lib.lib().ddmp_gemm_fused_bf16_supported(M, K, n) & 1
+    torch.manual_seed(n + K + M)
+    ab, a = rb(torch.randn(n, K) + 0.2)
+    w = torch.randn(M, K) / K ** 0.5
+    wq = w.to(BF).double()
+    bias = torch.randn(M)
+    ad, wd = ab.to(dev), w.to(dev)
+    ref = a @ wq.t() + bias.double()
+    atol = 3e-6 * float((a.abs() @ wq.abs().t()).max())
+    sums = torch.zeros(2 * M, dtype=torch.float64, device=dev)
+    y = ops.gemm_nt_stats(ad, wd, sums, bias=bias.to(dev))
+    assert y.dtype == BF and y.shape == (n, M)
+    nbad, worst = close_bf16(y, ref, atol)
+    assert nbad == 0, worst
+    yd = y.double().cpu()
+    assert relerr(sums[:M], yd.sum(0)) < 1e-12 and relerr(sums[M:], (yd * yd).sum(0)) < 1e-12
+    nbad, worst = close_bf16(ops.gemm_nt(ad, wd, bias=bias.to(dev)), ref, atol)    # (the plain form: either kernel)
+    assert nbad == 0, worst
+    sc, sh = torch.rand(K) + 0.5, torch.randn(K) * 0.3
+    y2 = ops.gemm_nt_stats(ad, wd, sums, pro=(sc.to(dev), sh.to(dev)))
+    z = f_ref(a, sc.double(), sh.double()).float().to(BF).double()
+    assert relerr(y2, z @ wq.t()) < 4e-3
+    yd = y2.double().cpu()
+    assert relerr(sums[:M], yd.sum(0)) < 1e-12 and relerr(sums[M:], (yd * yd).sum(0)) < 1e-12
+    for _ in range(3):                                                              # stable from launch to launch
+        assert torch.equal(ops.gemm_nt_stats(ad, wd, sums, pro=(sc.to(dev), sh.to(dev))), y2)
+
+
+@pytest.mark.parametrize("n,cin,cout", [(66000, 256, 512), (70001, 512, 512), (33000, 128, 256), (40000, 256, 256)])
+def test_gemm_bnbwd_bf16_fused_matches_composition(dev, n, cin, cout, monkeypatch):
+    """bf16 dgrad / wgrad with the BatchNorm+LeakyReLU backward rebuilt on the operand load == ddmp_bn_bwd_apply_bf16 followed
+    by the plain GEMMs: the rebuilt dY is rounded to bf16 exactly as the pass would have stored it, so the products agree to
+    float32 accumulation order; and == the float64 formula on the rounded operands."""
+    from dual_dmp_amd import ops
+    if os.environ.get("DDMP_GEMM_RR") == "0":
+        pytest.skip("fused bf16 GEMMs not available")
+    # (512 <- 512 is not DISPATCHED by the engine -- it measured slower than the separate pass -- but the kernels take it)
+    torch.manual_seed(n + cin)
+    dzb, dz = rb(torch.randn(n, cout))
+    ybb, yb = rb(torch.randn(n, cout) * 2 + 0.5)
+    pb, p = rb(torch.randn(n, cin))
+    w = torch.randn(cout, cin) / cout ** 0.5
+    bn4 = torch.stack([torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(cout), torch.rand(cout) + 0.5])
+    c10 = torch.stack([torch.randn(cout) * 0.1, torch.randn(cout) * 0.1])
+    dzg, ybg, wg, pg, bn4g, c10g = (t.to(dev) for t in (dzb, ybb, w, pb, bn4, c10))
+    dy = torch.empty_like(dzg)
+    sums = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    ops.bn_bwd_apply(dzg, ybg, bn4g, c10g, dy, sums)
+    dyd = dy.double().cpu()
+    nbad, worst = close_bf16(dy, bn_bwd_ref(dz, yb, bn4, c10), 2e-6)
+    assert nbad == 0, worst
+    dx = ops.gemm_nn_bnbwd(dzg, ybg, wg, bn4g, c10g)
+    assert dx.dtype == BF and dx.shape == (n, cin)
+    wq = w.to(BF).double()
+    atol = 3e-6 * float((dyd.abs() @ wq.abs()).max())
+    nbad, worst = close_bf16(dx, dyd @ wq, atol)
+    assert nbad == 0, worst
+    dw = ops.gemm_tn_bnbwd(dzg, ybg, pg, bn4g, c10g)
+    assert dw.dtype == torch.float32 and relerr(dw, dyd.t() @ p) < 1e-5
+    assert relerr(dw, ops.gemm_tn(dy, pg)) < 2e-6                                   # same operands, same arithmetic
+
+
 @pytest.mark.parametrize("n,M,K", [(1000, 64, 32), (3000, 512, 512), (2049, 512, 256), (2500, 256, 512), (900, 32, 64),
-                                    (1300, 128, 256), (130, 256, 256)])
+                                    (1300, 128, 256), (130, 256, 256), (66000, 512, 256), (33001, 256, 512), (20500, 128, 128)])
 def test_gemm_nn_bf16(dev, n, M, K):
     from dual_dmp_amd import ops
     torch.manual_seed(n + K + M)
