@@ -388,12 +388,14 @@ def main():
 
     for _ in range(args.warmup):
         tr.step().item()
+    ops.trace_marker()                   # (brackets the timed region in a rocprofv3 trace; outside the clock)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step().item()          # the reference's per-step sync (main.py:113)
     sync()
     elapsed = time.perf_counter() - t0
+    ops.trace_marker()
     scale_overflow = None                # f16x3 GEMM mode: operands that outgrew their scale are redone on the device
     healed = 0                           # (gemm_f16s.inc); only non-finite operands are an error
     try:

@@ -477,6 +477,11 @@ static bool rr_enabled() {
     return e == 1;
 }
 static const int64_t kRRMinRows = env_rows("DDMP_RR_MIN_ROWS", 20000);
+// (given the f16x3 row-panel route: wide output, f16 mode) does the call take the row-register kernel?
+static inline bool rr_route_ok(int64_t n_rows, int KD, int64_t lda, int64_t lda2) {
+    return rr_enabled() && KD >= 64 && KD <= 512 && n_rows >= kRRMinRows &&
+           n_rows * lda * 4 < ((int64_t)1 << 32) && n_rows * lda2 * 4 < ((int64_t)1 << 32);      // (32-bit lane offsets)
+}
 // f16 split mode (gemm_f16s.inc): 0 | 13; operand scale slots of the NEXT ddmp_gemm_* call on this host thread
 static int gemm_f16();
 struct ScaleCtx {
@@ -507,7 +512,8 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
                          int64_t ldw, int transpose, void* planes, float* Y, int64_t ldy, int n_rows, int KD, int MD,
                          const float* bias, const float* ps, const float* psh, const float* pc1, const float* pc0,
                          float slope, hipStream_t st, double* stats = nullptr, double* sums = nullptr,
-                         ScaleCtx ctx = ScaleCtx()) {
+                         ScaleCtx ctx = ScaleCtx(), const float* red_yp = nullptr, int64_t red_ldyp = 0,
+                         const float* const* red_bn4 = nullptr /* scale, shift, mean, rstd: stats = the backward reductions */) {
     // wide outputs: 128 x 512 | 256 x 256 blocks (64 x 128 per wave); narrow outputs (MD <= 128): 512-row blocks, 64 x 32 NJ
     const int WC = MD > 256 ? 4 : MD > 128 ? 2 : 1, WR = 8 / WC;
     const int NJ = MD > 128 ? 4 : MD > 64 ? 4 : MD > 32 ? 2 : 1;
@@ -526,9 +532,7 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
         hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
                            transpose ? KD : MD, transpose ? MD : KD, wscale);
-        const bool rr = rr_enabled() && KD >= 64 && KD <= kMaxProK && n_rows >= kRRMinRows &&
-                        (int64_t)n_rows * lda * 4 < ((int64_t)1 << 32) &&                 // (32-bit lane offsets)
-                        (PM != 2 || (int64_t)n_rows * lda2 * 4 < ((int64_t)1 << 32));
+        const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0);
         hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
                            (_Float16*)planes, (const float*)wscale);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
@@ -542,12 +546,17 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
             slots = std::max(8, slots / 8 * 8);
             dim3 rgrid((unsigned)(slots * n_halves)), rblock(256);
             for (int heal = 0; heal <= (prime ? 0 : 1); ++heal) {
-                if (PM != 2 && stats)
-                    hipLaunchKernelGGL((gemm_rr_kernel<PM == 2 ? 0 : PM, true, 3>), rgrid, rblock, 0, st, A, lda, A2, lda2,
+                if (PM == 0 && stats && red_yp)
+                    hipLaunchKernelGGL((gemm_rr_kernel<0, 2, 3>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP,
+                                       Y, ldy, n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, slot,
+                                       (const float*)wscale, target, heal, red_yp, red_ldyp, red_bn4[0], red_bn4[1], red_bn4[2],
+                                       red_bn4[3]);
+                else if (PM != 2 && stats)
+                    hipLaunchKernelGGL((gemm_rr_kernel<PM == 2 ? 0 : PM, 1, 3>), rgrid, rblock, 0, st, A, lda, A2, lda2,
                                        (const _Float16*)Bh, MP, Y, ldy, n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles,
                                        stats, slot, (const float*)wscale, target, heal);
                 else
-                    hipLaunchKernelGGL((gemm_rr_kernel<PM, false, PM == 2 ? 2 : 3>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP,
+                    hipLaunchKernelGGL((gemm_rr_kernel<PM, 0, PM == 2 ? 2 : 3>), rgrid, rblock, 0, st, A, lda, A2, lda2, (const _Float16*)Bh, MP,
                                        Y, ldy, n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, slot,
                                        (const float*)wscale, target, heal);
             }
@@ -890,6 +899,34 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
 
 
 // ---- BatchNorm+LeakyReLU backward fused into the operand load of the two GEMMs that consume dY (agg-first layers)
+// dgrad of a transform-first layer with the NEXT BatchNorm-backward reductions from its epilogue (row-register kernel):
+//   out[n, K] = A[n, M] . W[M, K]   and   sums2[2K] = (sum_rows g, sum_rows g yhat) of out as the gradient behind the previous
+//   layer's BatchNorm+LeakyReLU (Yp = that layer's conv output [n, K]; scale, shift, mean, rstd = its bn4 rows) --
+//   what ddmp_bn_bwd_reduce_f32(out, Yp, ...) returns, without reading out again
+extern "C" int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows) {
+    return gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows && n_rows >= kPanelMinRows &&
+                   M % 32 == 0 && M >= 64 && M <= kMaxProK && K > 128 && K <= 512 && K % 4 == 0 ? 1 : 0;
+}
+extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
+                                      int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale,
+                                      const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
+                                      void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                                      ddmp_stream stream) {
+    const ScaleCtx ctx = take_scale_ctx();
+    ARG_TRY(A && W && out && Yp && scale && shift && mean && rstd && sums2 && n_rows > 0 && n_rows < INT32_MAX);
+    ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ld_out >= K && ldyp >= K);
+    ARG_TRY(aligned16(A) && aligned16(W));
+    if (!ddmp_gemm_nn_bnred_supported(M, K, n_rows) || !rr_route_ok(n_rows, M, lda, 0) ||
+        !panel_ok(M, K, out, ld_out, workspace, workspace_bytes, n_rows))
+        return DDMP_EINVAL;
+    if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, K)) return DDMP_EWORKSPACE;
+    const float* bn4[4] = {scale, shift, mean, rstd};
+    launch_panel<0>(gemm_mode(), A, lda, nullptr, 0, W, ldw, 1, workspace, out, ld_out, (int)n_rows, M, K, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, slope, (hipStream_t)stream, (double*)stats_ws, sums2, ctx, Yp, ldyp, bn4);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
 extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows) {
     if (gemm_mode() == 0 || !panel_enabled() || !tn_panel_enabled() || n_rows < kTnPanelMinRows) return 0;
     const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin > 128 && cin <= 512;

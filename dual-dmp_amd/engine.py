@@ -434,6 +434,22 @@ class GcnEngine:
             ops.spmm(g, src, out=dst[:n])
             return False
 
+        # OFF by default: measured at 1M faces (round 3, interleaved A/B): the fused dgrads cost +2.4 ms per step for the 1.56 ms
+        # of bn_bwd_reduce passes they replace (step 48.7 -> 49.6 ms) -- 128 strided loads of Yp and 256 float64 FMAs per lane
+        # and tile in the epilogue of a kernel that already runs against the socket power cap.  DDMP_GEMM_BNRED=1 for A/B.
+        fuse_dgrad_red = (getattr(ops, "gemm_nn_bnred_supported", None) is not None and isinstance(self.comm, NoComm)
+                          and os.environ.get("DDMP_GEMM_BNRED", "0") == "1")
+
+        def dgrad_to_dz(dH, W, dZ, l):
+            """dZ of layer l-1 = dH . W (transform-first layer l > 0); with that layer's BatchNorm-backward column reductions
+            from the GEMM epilogue where the kernel exists (one device: across devices the sums are all-reduced anyway, but
+            the halo rows of dZ are not this rank's to count -- the epilogue sums owned rows only, which is what n selects)."""
+            if fuse_dgrad_red and ops.gemm_nn_bnred_supported(L.cout[l], L.cin_p[l], n, self.dtype):
+                ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n)
+                return True
+            ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+            return False
+
         for l in range(11, -1, -1):
             i = l + 1
             co, ci = L.cout[l], L.cin_p[l]
@@ -472,7 +488,7 @@ class GcnEngine:
                 Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
                 kz, dZ = take(ci)
                 self._scales(l, 1)
-                ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+                have_sums = dgrad_to_dz(dH, W, dZ, l)
                 wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
                 release(kh)
                 continue
@@ -506,7 +522,7 @@ class GcnEngine:
                 if l > 0:
                     kz, dZ = take(ci)
                     self._scales(l, 1)
-                    ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+                    have_sums = dgrad_to_dz(dH, W, dZ, l)
                 wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
                 release(kh)
         if side is not None:                                     # the gradients are complete when this pass returns

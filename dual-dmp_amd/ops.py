@@ -92,6 +92,11 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def trace_marker():
+    """Launch the library's marker kernel on the current stream (cuts a rocprofv3 trace to a region: bench.py)."""
+    check(_lib.lib().ddmp_trace_marker(_stream()), "ddmp_trace_marker")
+
+
 def set_gemm_mode(mode: int):
     """6 = bf16x6 split MFMA (f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA; 13 = f16x3 split MFMA
     in the row-panel kernels (f32-class accuracy, scaled operands: see gemm_next_scales), bf16x6 elsewhere."""
@@ -400,6 +405,35 @@ def gemm_nn(a, w, out=None, n_rows=None):
     with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nn(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream())
     check(st, "ddmp_gemm_nn")
+    return out
+
+
+def gemm_nn_bnred_supported(M, K, n_rows, dtype=torch.float32):
+    """Does gemm_nn_bnred exist for a dgrad M -> K over n_rows rows (float32 features, row-register kernel)?"""
+    return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_nn_bnred_supported(int(M), int(K), int(n_rows)))
+
+
+def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None):
+    """out[n,K] = a[n,M] @ w[M,K] AND sums (float64 [2K]) = bn_bwd_reduce(out, yp, bn4): the BatchNorm-backward column
+    reductions of `out` as the gradient behind the previous layer's BatchNorm+LeakyReLU (yp: that layer's conv output),
+    from the GEMM epilogue -- one read of yp instead of a pass over out and yp."""
+    a, lda = _mat(a, "a")
+    w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
+    yp, ldyp = _mat(yp, "yp")
+    n = a.shape[0] if n_rows is None else n_rows
+    M, K = w.shape
+    if out is None:
+        out = torch.empty((n, K), dtype=torch.float32, device=a.device)
+    out, ldo = _mat(out, "out")
+    L = _lib.lib()
+    nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
+    sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
+    ws = Workspace.get(nb + sb, a.device)
+    with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        st = L.ddmp_gemm_nn_bnred_f32(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
+                                      _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb,
+                                      _stream())
+    check(st, "ddmp_gemm_nn_bnred_f32")
     return out
 
 

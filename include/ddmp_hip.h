@@ -274,6 +274,15 @@ int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t 
  *     dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0        (a, b, c1, c0 per column, from ddmp_bn_bwd_prepare_f32)
  * ddmp_gemm_bnbwd_supported(cout, cin, n_rows) says whether BOTH fused GEMMs exist for a layer of that shape and row
  * count in the current GEMM mode (the panel kernels they live in are used from ~30k rows); the conv-bias gradient (column sums of dY) is exactly zero in exact arithmetic and is written as 0. */
+/* dgrad of a transform-first layer with the NEXT BatchNorm-backward column reductions from its epilogue (round 3, row-register
+ * kernel): out[n,K] = A[n,M] . W[M,K] and sums2[2K] = what ddmp_bn_bwd_reduce_f32(out, Yp, scale, shift, mean, rstd) returns,
+ * Yp [n,K] = the previous layer's conv output; stats_ws >= ddmp_gemm_nt_stats_workspace_bytes(n_rows, K) */
+int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows);
+int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
+                           int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
+                           void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                           ddmp_stream stream);
 int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows);
 int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,
                            float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b,
@@ -415,6 +424,8 @@ int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* plan, void* T, int
 int ddmp_comm_allreduce_sum(ddmp_comm* comm, void* buf, int64_t n, int is_f64, ddmp_stream stream);
 int ddmp_comm_allgather(ddmp_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, ddmp_stream stream);
 /* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
+/* a one-thread kernel named ddmp_trace_marker_kernel: brackets a region in a rocprofv3 kernel trace (measurement aid) */
+int ddmp_trace_marker(ddmp_stream stream);
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
 

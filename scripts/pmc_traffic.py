@@ -24,15 +24,19 @@ def table(db, frag):
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
     pmc, info, kd, ks = table(db, "pmc_event"), table(db, "info_pmc"), table(db, "kernel_dispatch"), table(db, "info_kernel_symbol")
+    # only the dispatches between bench.py's two trace markers (its timed region), when the trace has them
+    marks = db.execute("select k.start, k.end from {kd} k join {ks} s on k.kernel_id = s.id where s.display_name like "
+                       "'%ddmp_trace_marker_kernel%' order by 1".format(kd=kd, ks=ks)).fetchall()
+    win = " and k.start > %d and k.end < %d" % (marks[0][1], marks[-1][0]) if len(marks) >= 2 else ""
     q = ("select s.display_name, count(distinct k.id), sum(p.value), sum(distinct (k.end - k.start) * 1000003 + k.id) "
          "from {pmc} p join {info} i on p.pmc_id = i.id join {kd} k on p.event_id = k.event_id "
-         "join {ks} s on k.kernel_id = s.id where i.name = ? group by 1").format(pmc=pmc, info=info, kd=kd, ks=ks)
+         "join {ks} s on k.kernel_id = s.id where i.name = ?{win} group by 1").format(pmc=pmc, info=info, kd=kd, ks=ks, win=win)
     out = {}
     for name, n, v, _ in db.execute(q, (counter,)):
         out[name] = [n, v]
     dur = {}
     for name, ns in db.execute("select s.display_name, sum(k.end - k.start) from {kd} k join {ks} s on k.kernel_id = s.id "
-                               "group by 1".format(kd=kd, ks=ks)):
+                               "where 1{win} group by 1".format(kd=kd, ks=ks, win=win)):
         dur[name] = ns
     return out, dur
 
@@ -44,7 +48,7 @@ def short(name):
 
 
 def family(k):
-    if "gemm" in k or "split_w" in k or "reduce_splits" in k:
+    if "gemm" in k or "split_w" in k or "reduce_splits" in k or "w_planes" in k or "f16s_" in k:
         return "gemm"
     if "spmm" in k:
         return "spmm"

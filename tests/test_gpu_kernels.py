@@ -209,6 +209,32 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("n,M,K", [(66001, 256, 512), (40000, 128, 256), (33000, 512, 512), (20300, 64, 256)])
+def test_gemm_nn_with_bn_backward_reductions(dev, n, M, K):
+    """dgrad of a transform-first layer with the next BatchNorm-backward column reductions from its epilogue (row-register
+    kernel) == gemm_nn followed by bn_bwd_reduce of its output, and == the float64 formulas."""
+    from dual_dmp_amd import ops
+    if not ops.gemm_nn_bnred_supported(M, K, n):
+        pytest.skip("row-register f16x3 kernels not active in this configuration")
+    torch.manual_seed(n + M + K)
+    dh, w = torch.randn(n, M) * 1e-2, torch.randn(M, K) / M ** 0.5
+    yp = torch.randn(n, K) * 2 + 0.3
+    bn4 = torch.stack([torch.rand(K) + 0.5, torch.randn(K), torch.randn(K) * 0.1 + 0.3, torch.rand(K) + 0.5])
+    dhg, wg, ypg, bn4g = dh.to(dev), w.to(dev), yp.to(dev), bn4.to(dev)
+    sums = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    out = ops.gemm_nn_bnred(dhg, wg, ypg, bn4g, sums)
+    ref = dh.double() @ w.double()
+    assert relerr(out, ref) < 2e-6
+    assert torch.equal(out, ops.gemm_nn(dhg, wg))                                   # the same kernel without the epilogue
+    sums_pass = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+    ops.bn_bwd_reduce(out, ypg, bn4g, sums2=sums_pass)
+    assert relerr(sums, sums_pass) < 1e-9, relerr(sums, sums_pass)                  # float64 sums of the same float32 terms
+    a, b, mu, rs = (bn4[i].double() for i in range(4))
+    g = out.double().cpu() * torch.where(yp.double() * a + b > 0, 1.0, 0.01)
+    ref_s = torch.cat([g.sum(0), (g * (yp.double() - mu) * rs).sum(0)])
+    assert relerr(sums, ref_s) < 1e-5
+
+
 @pytest.mark.parametrize("n,K,M", [(20777, 512, 512), (70001, 64, 256), (21000, 96, 384), (513, 256, 128), (130, 8, 32),
                                    (30001, 64, 128), (20480, 32, 64), (22222, 128, 32)])
 def test_gemm_nt_stats_matches_bn_stats(dev, gemm_mode, n, K, M):
