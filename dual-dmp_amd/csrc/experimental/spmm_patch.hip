@@ -30,7 +30,6 @@ using namespace ddmp;
 
 constexpr int kRB = 64;            // rows per chunk (= ddmp::kChunkRows: the patch tables are per 64 rows)
 constexpr int kMaxE = kRB * 16;    // CSR entries per chunk
-constexpr int kNB = 4;             // patch buffers (the exact-count prologue below is written for 4)
 
 template <typename T> struct Lane;                                  // one lane = 16 bytes of a row
 template <> struct Lane<float> {
@@ -63,7 +62,9 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 };
 
 // KD: copies per wave and slab of the patch (8 rows each, 4 waves): the patch buffer holds 32 KD rows
-template <typename T, int KD, bool PRO, bool RED>
+// NB: patch buffers (2: 41-57 KB of LDS per workgroup, two to three workgroups per CU hide each other's copy latency and
+// barriers; 4: the round-2 form, one workgroup per CU pipelining three slabs ahead)
+template <typename T, int KD, bool PRO, bool RED, int NB>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
     const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     constexpr int KR = RED ? 2 : 0;                              // copies per wave and slab of the chunk's own Yp rows
     constexpr int NST = 2;                                       // output stores per lane and slab
     constexpr int kBuf = PR * 128 + (RED ? kRB * 128 : 0);       // bytes per buffer
+    constexpr int kNB = NB;
     constexpr int NWAIT = (KD + KR) * (kNB - 2) + NST * (kNB - 1);   // VMEM operations younger than the copies of slab s
     static_assert(NWAIT <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -146,9 +148,9 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     // The slab loop is unrolled over the four buffers with COMPILE-TIME buffer addresses: the compiler orders a ds_read
     // behind every LDS-DMA it cannot prove disjoint (a run-time buffer index costs a vmcnt(0) -- a full drain -- before
     // the first read of every slab; measured 2x on the whole kernel).
-    if (0 < n_slabs) copy(0, bufs);
-    if (1 < n_slabs) copy(1, bufs + kBuf);
-    if (2 < n_slabs) copy(2, bufs + 2 * kBuf);
+#pragma unroll
+    for (int i = 0; i < kNB - 1; ++i)
+        if (i < n_slabs) copy(i, bufs + i * kBuf);
     auto slab = [&](int s, auto bc) {
         constexpr int B = decltype(bc)::value;
         // the copies of slab s have landed (mine: counted wait; everybody's: barrier); all waves are done with slab s-1
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         constexpr int ND = (KD + KR) * (kNB - 2);
         if (!full || s + kNB - 1 > n_slabs) wait_vm_barrier<0>();
         else if (s == 0) wait_vm_barrier<ND>();
-        else if (s == 1) wait_vm_barrier<ND + NST>();
-        else if (s == 2) wait_vm_barrier<ND + 2 * NST>();
+        else if (s == 1 && kNB > 2) wait_vm_barrier<ND + NST>();
+        else if (s == 2 && kNB > 3) wait_vm_barrier<ND + 2 * NST>();
         else wait_vm_barrier<NWAIT>();
         if (s + kNB - 1 < n_slabs) copy(s + kNB - 1, bufs + ((B + kNB - 1) % kNB) * kBuf);
         const unsigned char* pb = bufs + B * kBuf + sl * 16;
@@ -255,27 +257,38 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     for (int s = 0; s < n_slabs; s += kNB) {
         slab(s, std::integral_constant<int, 0>());
         if (s + 1 < n_slabs) slab(s + 1, std::integral_constant<int, 1>());
-        if (s + 2 < n_slabs) slab(s + 2, std::integral_constant<int, 2>());
-        if (s + 3 < n_slabs) slab(s + 3, std::integral_constant<int, 3>());
+        if constexpr (kNB > 2) {
+            if (s + 2 < n_slabs) slab(s + 2, std::integral_constant<int, 2>());
+            if (s + 3 < n_slabs) slab(s + 3, std::integral_constant<int, 3>());
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
 }
 
-template <typename T, int KD, bool PRO, bool RED>
+int patch_nb() {                                                  // DDMP_SPMM_PATCH_NB=2|4 (A/B)
+    static int nb = 0;
+    if (!nb) {
+        const char* e = getenv("DDMP_SPMM_PATCH_NB");
+        nb = (e && atoi(e) == 4) ? 4 : 2;
+    }
+    return nb;
+}
+
+template <typename T, int KD, bool PRO, bool RED, int NB>
 size_t patch2_lds(int C) {
     const int PR = 32 * KD;
     const size_t buf = (size_t)PR * 128 + (RED ? kRB * 128 : 0);
-    return kNB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4;
+    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4;
 }
 
-template <typename T, int KD, bool PRO, bool RED>
-int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
-                  const float* psh, float slope, hipStream_t st, RedArgs red) {
+template <typename T, int KD, bool PRO, bool RED, int NB>
+int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
+                    const float* psh, float slope, hipStream_t st, RedArgs red) {
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
-    const size_t lds = patch2_lds<T, KD, PRO, RED>(C);
-    auto kern = spmm_patch2_kernel<T, KD, PRO, RED>;
+    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C);
+    auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB>;
     static bool attr_done = false;                               // > 64 KB of dynamic LDS needs the attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -285,6 +298,13 @@ int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ld
                        ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
     LAUNCH_TRY();
     return DDMP_OK;
+}
+
+template <typename T, int KD, bool PRO, bool RED>
+int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
+                  const float* psh, float slope, hipStream_t st, RedArgs red) {
+    if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    return launch_patch2nb<T, KD, PRO, RED, 2>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
 template <typename T, bool PRO, bool RED>
