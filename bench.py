@@ -233,7 +233,7 @@ def pmc_traffic(name, dtype, launches_per_step):
     for k in d.get("per_kernel", []):
         kn = k["kernel"]
         fam = ("spmm" if "spmm" in kn else "gemm_tn" if "gemm_tn" in kn else
-               "gemm_rows" if ("gemm_rows" in kn or "gemm_panel" in kn) else kn)
+               "gemm_rows" if ("gemm_rows" in kn or "gemm_panel" in kn or "gemm_rr" in kn) else kn)
         want = {"spmm": "spmm", "gemm_tn": "gemm_tn", "gemm_nt": "gemm_rows", "gemm_nn": "gemm_rows"}.get(name, name)
         if fam == want or (name == "gemm" and fam.startswith("gemm_")):
             tot_b += (k["hbm_read_GB"] + k["hbm_write_GB"]) * 1e9
