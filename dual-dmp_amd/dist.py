@@ -318,6 +318,42 @@ class NativeComm:
         torch.cuda.synchronize(self.device)
         self.dist.barrier()
 
+    def self_check(self, plan: "HaloPlan") -> bool:
+        """World size > 1, before the first step: push a tensor of GLOBAL row ids through this communicator's grouped halo
+        exchange and a float64 vector through its all-reduce, and compare with what torch.distributed delivers for the
+        same plan (all_to_all_single / all_reduce: the path the gloo world-2 tests cover).  Every rank returns the same
+        verdict (the flags are all-reduced through torch.distributed): False = do not use this backend.  The native
+        send/recv path cannot be run with peers in the build loop (one-GPU boxes; RCCL refuses two ranks on one device),
+        so it proves itself on the job's own plan before it is trusted."""
+        dev = self.device
+        ok = 1.0
+        try:
+            with ops.on_device(dev):
+                ids = torch.from_numpy(np.asarray(plan.local_ids, dtype=np.float64)).to(dev)
+                t = torch.zeros((plan.n_cols, 4), dtype=torch.float32, device=dev)
+                t[: plan.n_rows, 0] = (ids[: plan.n_rows] % 8191.0).float()
+                t[: plan.n_rows, 1] = torch.div(ids[: plan.n_rows], 8191.0, rounding_mode="floor").float()
+                t[: plan.n_rows, 2] = float(self.rank)
+                ref = t.clone()
+                send = ref[: plan.n_rows].index_select(0, torch.from_numpy(plan.send_idx).to(dev)).contiguous()
+                recv = ref[plan.n_rows: plan.n_cols]
+                self.dist.all_to_all_single(recv, send, output_split_sizes=list(plan.recv_counts),
+                                            input_split_sizes=list(plan.send_counts))
+                sums = torch.arange(8, dtype=torch.float64, device=dev) + self.rank
+                sums_ref = sums.clone()
+                self.dist.all_reduce(sums_ref)
+                self.halo_exchange_native(plan, t, sums)
+                torch.cuda.synchronize(dev)
+                want = ids[plan.n_rows: plan.n_cols]
+                got = t[plan.n_rows: plan.n_cols, 0].double() + 8191.0 * t[plan.n_rows: plan.n_cols, 1].double()
+                if not (torch.equal(t, ref) and torch.equal(got, want) and torch.equal(sums, sums_ref)):
+                    ok = 0.0
+        except Exception:       # noqa: BLE001
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
     def close(self):
         """Destroy the halo plans and the communicator (idempotent; also run by the finalizer)."""
         plans, self._plans = self._plans, {}
@@ -873,4 +909,12 @@ def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnflo
         nets = (PosNet(device), NormalNet(device))
     posnet, normnet = nets
     sharded = ShardedData(dataset, n_mesh, rank, world)
+    if isinstance(backend, NativeComm) and backend.world_size > 1 and not kw.get("_skip_self_check"):
+        good = backend.self_check(sharded.fplan) and (backend_pos is None or backend_pos.self_check(sharded.vplan))
+        if not good:
+            import warnings
+            warnings.warn("the native RCCL backend failed its self-check against torch.distributed on this job's halo plan: "
+                          "using torch.distributed (blocking collectives, one stream)")
+            backend, backend_pos = TorchDistComm(), None
+    kw.pop("_skip_self_check", None)
     return DistributedTrainer(posnet, normnet, sharded, n_mesh, backend, device, bnfloop=bnfloop, backend_pos=backend_pos, **kw)

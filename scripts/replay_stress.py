@@ -1,6 +1,8 @@
 """Eager / hipGraph / two-stream / two-stream hipGraph iterations of one small mesh, N times over in one process: losses, outputs
 and parameters must be bit-identical across all of them (tests/test_gpu_path.py::test_graph_replay_is_bit_identical_to_eager runs it
-once; this is the stress form that found a 5 % flake).  usage: replay_stress.py [repetitions] [f32|bf16]"""
+once; this is the stress form that found a 5 % flake).  usage: replay_stress.py [repetitions] [f32|bf16] [big]
+`big`: a 48,400-face torus instead of the 532-face grid -- both nets above the 20k-row threshold of the row-register / row-panel
+GEMMs and of the fused BatchNorm routes, so the two-stream graph runs those kernels beside each other."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dual_dmp_amd import synth
@@ -8,7 +10,8 @@ from dual_dmp_amd.datamaker import dataset_from_meshes
 from dual_dmp_amd.networks import PosNet, NormalNet
 from dual_dmp_amd.trainer import FusedTrainer
 dev = torch.device("cuda:0")
-v, f = synth.open_grid(20, 15)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+v, f = synth.torus(220, 110) if BIG else synth.open_grid(20, 15)
 v, f = synth.permute_vertices(v, f, 4)
 gt, noisy, smooth = synth.make_triplet(v, f)
 data = dataset_from_meshes(noisy, smooth); data.to(dev)

@@ -29,6 +29,8 @@ def main():
     torch.manual_seed(0)
     nets = (PosNet(dev), NormalNet(dev))
     tr = D.make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=2, nets=nets, losses=losses)
+    if isinstance(tr.backend, D.NativeComm):                               # the start-up self-check of the native backend
+        assert tr.backend.self_check(tr.sd.fplan) and tr.backend_pos.self_check(tr.sd.vplan), "NativeComm.self_check"
     tr.epoch = 100                                                          # BNF gate open (main.py:101-102)
     hist = []
     for _ in range(steps):
