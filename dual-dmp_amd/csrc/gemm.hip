@@ -532,7 +532,11 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
         hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
                            transpose ? KD : MD, transpose ? MD : KD, wscale);
-        const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0);
+        // PM = 2 with two column halves (512 <- 512 dgrad): the halves are separate, freely drifting workgroups and BOTH stream
+        // (dZ, Y) -- PMC: the family read 27.3 GB per step for 18.4 GB algorithmic, the second half's rows mostly missing the
+        // XCD's L2 -- while the row-panel kernel reads them once at the same speed (1499 vs 1490-1511 us): that shape keeps it.
+        static const bool rr_pm2_wide = env_rows("DDMP_RR_PM2_WIDE", 0) == 1;
+        const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0) && !(PM == 2 && MD > kRRCols && !rr_pm2_wide);
         hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
                            (_Float16*)planes, (const float*)wscale);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);

@@ -209,6 +209,50 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
 
 
+def _rr_shapes(seed, count):
+    """Random shapes inside the row-register kernel's domain: >= 20k rows (ragged last tiles, fewer tiles than workgroup slots
+    and many more), contraction 64..512 in steps of 32, 129..512 output columns in steps of 4 (padded 256 / 512 panels)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        n = int(rng.choice([20000 + int(rng.integers(0, 4000)), 33000 + int(rng.integers(0, 300)), 70000 + int(rng.integers(0, 9000))]))
+        out.append((n, int(rng.integers(2, 17)) * 32, int(rng.integers(33, 129)) * 4))
+    return out
+
+
+@pytest.mark.parametrize("n,K,M", _rr_shapes(3, 10))
+def test_row_register_gemm_random_shapes(dev, f16x3, n, K, M):
+    """Forward (bias; prologue; statistics), dgrad and the BatchNorm-backward dgrad of the row-register f16x3 kernel on random
+    shapes against float64, each launched twice (bit-stable)."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + K + M)
+    a, w, bias = torch.randn(n, K), torch.randn(M, K) / K ** 0.5, torch.randn(M)
+    sc, sh = torch.rand(K) + 0.5, torch.randn(K)
+    ad, wd = a.to(dev), w.to(dev)
+    ref = a.double() @ w.double().t()
+    y = ops.gemm_nt(ad, wd, bias=bias.to(dev))
+    assert relerr(y, ref + bias.double()) < 2e-6
+    assert torch.equal(ops.gemm_nt(ad, wd, bias=bias.to(dev)), y)
+    sums = torch.zeros(2 * M, dtype=torch.float64, device=dev)
+    y2 = ops.gemm_nt_stats(ad, wd, sums, pro=(sc.to(dev), sh.to(dev)))
+    assert relerr(y2, f_ref(a.double(), sc.double(), sh.double()) @ w.double().t()) < 2e-6
+    yd = y2.double().cpu()
+    assert relerr(sums[:M], yd.sum(0)) < 1e-6 and relerr(sums[M:], (yd * yd).sum(0)) < 1e-6
+    if M % 32 == 0 and K > 128:                                      # as a dgrad: contraction M, output K
+        g = torch.randn(n, M)
+        dx = ops.gemm_nn(g.to(dev), w.to(dev))
+        assert relerr(dx, g.double() @ w.double()) < 2e-6
+        if ops.gemm_bnbwd_supported(M, K, n):
+            yb = torch.randn(n, M) * 2 + 0.5
+            bn4 = torch.stack([torch.rand(M) + 0.5, torch.randn(M), torch.randn(M), torch.rand(M) + 0.5])
+            c10 = torch.stack([torch.randn(M) * 0.1, torch.randn(M) * 0.1])
+            a4, b4, k1, k0 = bn4[0].double(), bn4[1].double(), c10[0].double(), c10[1].double()
+            z = yb.double() * a4 + b4
+            dy = a4 * g.double() * torch.where(z > 0, 1.0, 0.01) + k1 * yb.double() + k0
+            dx = ops.gemm_nn_bnbwd(g.to(dev), yb.to(dev), w.to(dev), bn4.to(dev), c10.to(dev))
+            assert relerr(dx, dy @ w.double()) < 3e-6
+
+
 @pytest.mark.parametrize("n,M,K", [(66001, 256, 512), (40000, 128, 256), (33000, 512, 512), (20300, 64, 256)])
 def test_gemm_nn_with_bn_backward_reductions(dev, n, M, K):
     """dgrad of a transform-first layer with the next BatchNorm-backward column reductions from its epilogue (row-register
