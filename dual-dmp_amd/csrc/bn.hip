@@ -13,6 +13,7 @@
 //
 // Column layout: C/4 lanes (float4) per row, 256/(C/4) rows per workgroup step, grid-stride over rows.
 #include "b16_common.h"
+#include "finalize.h"
 
 #include <algorithm>
 
@@ -160,71 +161,54 @@ struct ColsumF {
     }
 };
 
-// partial[nblk][width] -> out[width] (double).  32 columns x 8 row-slices per workgroup; every slice keeps
-// 8 independent loads in flight (the serial form of this loop was latency-bound: 73 us per call).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nblk,
-                                                              int width, double* __restrict__ out) {
-    __shared__ double sm[256];
+// partial[nblk][2C] -> out[2C] (double) (+ the coefficients `fin` asks for: finalize.h).  32 columns x 8 row-slices per
+// workgroup, BOTH sums of a column in one thread; every slice keeps 8 independent loads per sum in flight (the serial form
+// of this loop was latency-bound: 73 us per call).  Order of additions per output: slice-strided, then the 8 slices.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                              double* __restrict__ out, FinalizeArgs fin) {
+    __shared__ double sm[2][256];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
-    double t = 0.0;
-    if (c < width) {
+    const int width = 2 * C;
+    double t0 = 0.0, t1 = 0.0;
+    if (c < C) {
         int b = sl;
         for (; b + 56 < nblk; b += 64) {
-            double v[8];
+            double v[8], w[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * width + c];
+            for (int u = 0; u < 8; ++u) {
+                v[u] = partial[(int64_t)(b + 8 * u) * width + c];
+                w[u] = partial[(int64_t)(b + 8 * u) * width + C + c];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t += v[u];
+            for (int u = 0; u < 8; ++u) {
+                t0 += v[u];
+                t1 += w[u];
+            }
         }
-        for (; b < nblk; b += 8) t += partial[(int64_t)b * width + c];
+        for (; b < nblk; b += 8) {
+            t0 += partial[(int64_t)b * width + c];
+            t1 += partial[(int64_t)b * width + C + c];
+        }
     }
-    sm[threadIdx.x] = t;
+    sm[0][threadIdx.x] = t0;
+    sm[1][threadIdx.x] = t1;
     __syncthreads();
-    if (sl == 0 && c < width) {
-        double r = 0.0;
+    if (sl == 0 && c < C) {
+        double r0 = 0.0, r1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r += sm[threadIdx.x + 32 * u];
-        out[c] = r;
+        for (int u = 0; u < 8; ++u) {
+            r0 += sm[0][threadIdx.x + 32 * u];
+            r1 += sm[1][threadIdx.x + 32 * u];
+        }
+        out[c] = r0;
+        out[C + c] = r1;
+        finalize_column(fin, c, r0, r1);
     }
 }
 
-__global__ void bn_prepare_kernel(const double* __restrict__ sums, double n_total, int C,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                  float momentum, float* __restrict__ scale, float* __restrict__ shift,
-                                  float* __restrict__ mean, float* __restrict__ rstd,
-                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, FinalizeArgs fin) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = sums[c] / n_total;
-    double var = sums[C + c] / n_total - mu * mu;   // biased
-    if (var < 0.0) var = 0.0;
-    const float muf = (float)mu;
-    const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    const float a = gamma[c] * rs;
-    scale[c] = a;
-    shift[c] = fmaf(-muf, a, beta[c]);
-    mean[c] = muf;
-    rstd[c] = rs;
-    if (running_mean) {
-        const double unb = n_total > 1.0 ? var * n_total / (n_total - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
-}
-
-__global__ void bn_bwd_prepare_kernel(const double* __restrict__ sums2, double n_total, int C,
-                                      const float* __restrict__ scale, const float* __restrict__ mean,
-                                      const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c0) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double db = sums2[c], dg = sums2[C + c];
-    dbeta[c] = (float)db;
-    dgamma[c] = (float)dg;
-    const double a = scale[c], r = rstd[c], mu = mean[c];
-    const double k1 = -a * r * dg / n_total;
-    c1[c] = (float)k1;
-    c0[c] = (float)(-a * db / n_total - k1 * mu);
+    if (c < fin.C) finalize_column(fin, c, sums[c], sums[fin.C + c]);
 }
 
 __global__ void f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
@@ -276,10 +260,10 @@ int run_colreduce(const F& f, int64_t n_rows, int C, int width, double* out, voi
     hipLaunchKernelGGL((colreduce_kernel<F>), dim3(nblk), dim3(256), 0, st, f, (int)n_rows, C, partial);
     LAUNCH_TRY();
     // partial rows are [2*C]; reduce the first `width` columns (width = C or 2C)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(2 * C, 32)), dim3(256), 0, st, partial, nblk,
-                       2 * C, out);
+    // (width = 2C: the coefficients armed by ddmp_bn_next_* ride on the second stage; C: only the first half is exported)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, partial, nblk, C, out,
+                       width == 2 * C ? finalize_take(C) : FinalizeArgs());
     LAUNCH_TRY();
-    (void)width;
     return DDMP_OK;
 }
 
@@ -293,6 +277,7 @@ extern "C" size_t ddmp_colreduce_workspace_bytes(int64_t n_rows, int C) {
 
 extern "C" int ddmp_bn_stats_f32(const float* Y, int64_t ldy, int64_t n_rows, int C, double* sums,
                                  void* ws, size_t ws_bytes, ddmp_stream stream) {
+    FinalizeScope fin_scope(sums, stream);
     ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && ldy % 4 == 0);
     StatsF<float> f{Y, ldy};
     return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
@@ -304,9 +289,11 @@ extern "C" int ddmp_bn_prepare_f32(const double* sums, double n_total, int C, co
                                    float* running_var, ddmp_stream stream) {
     ARG_TRY(sums && n_total > 0 && C > 0 && gamma && beta && scale && shift && mean && rstd);
     ARG_TRY((running_mean == nullptr) == (running_var == nullptr));
-    hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums,
-                       n_total, C, gamma, beta, eps, momentum, scale, shift, mean, rstd, running_mean,
-                       running_var);
+    FinalizeArgs f;
+    f.kind = 1; f.C = C; f.n_total = n_total; f.eps = eps; f.momentum = momentum;
+    f.in[0] = gamma; f.in[1] = beta;
+    f.out[0] = scale; f.out[1] = shift; f.out[2] = mean; f.out[3] = rstd; f.out[4] = running_mean; f.out[5] = running_var;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums, f);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -328,6 +315,7 @@ extern "C" int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float
                                       int64_t n_rows, int C, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, float slope, double* sums2,
                                       void* ws, size_t ws_bytes, ddmp_stream stream) {
+    FinalizeScope fin_scope(sums2, stream);
     ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && lddz >= C && ldy % 4 == 0 && lddz % 4 == 0);
     BwdReduceF<float> f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
@@ -338,8 +326,11 @@ extern "C" int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int 
                                        const float* mean, const float* rstd, float* dgamma, float* dbeta,
                                        float* c1, float* c0, ddmp_stream stream) {
     ARG_TRY(sums2 && n_total > 0 && C > 0 && scale && mean && rstd && dgamma && dbeta && c1 && c0);
-    hipLaunchKernelGGL(bn_bwd_prepare_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream,
-                       sums2, n_total, C, scale, mean, rstd, dgamma, dbeta, c1, c0);
+    FinalizeArgs f;
+    f.kind = 2; f.C = C; f.n_total = n_total;
+    f.in[0] = scale; f.in[1] = mean; f.in[2] = rstd;
+    f.out[0] = dgamma; f.out[1] = dbeta; f.out[2] = c1; f.out[3] = c0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums2, f);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -348,7 +339,7 @@ extern "C" int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float*
                                      int64_t lddy, int64_t n_rows, int C, const float* scale,
                                      const float* shift, const float* c1, const float* c0, float slope,
                                      double* dbias_sums, void* ws, size_t ws_bytes, ddmp_stream stream) {
-    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0 && dbias_sums);
+    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C));
     ARG_TRY(ldy >= C && lddz >= C && lddy >= C && ldy % 4 == 0 && lddz % 4 == 0 && lddy % 4 == 0);
     BwdApplyF<float> f{dZ, Y, scale, shift, c1, c0, dY, lddz, ldy, lddy, slope};
@@ -356,6 +347,12 @@ extern "C" int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float*
     const int nblk = colreduce_blocks(n_rows, C);
     const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
     if (!ws || ws_bytes < need) return DDMP_EWORKSPACE;
+    if (!dbias_sums) {                                           // dY only (its column sums are zero after BatchNorm)
+        hipLaunchKernelGGL((colreduce_kernel<BwdApplyF<float>>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, f, (int)n_rows,
+                           C, (double*)ws);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     double* tmp = (double*)ws + (size_t)nblk * 2 * C;
     int st = run_colreduce(f, n_rows, C, C, tmp, ws, (size_t)nblk * 2 * C * sizeof(double), (hipStream_t)stream);
     if (st != DDMP_OK) return st;
@@ -389,6 +386,7 @@ extern "C" int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_str
 // per lane, float32 arithmetic, float64 sums; C a power of two in [16, 1024]; workspace = ddmp_colreduce_workspace_bytes
 extern "C" int ddmp_bn_stats_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, int C, double* sums, void* ws,
                                   size_t ws_bytes, ddmp_stream stream) {
+    FinalizeScope fin_scope(sums, stream);
     ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && ldy % 8 == 0 && b16_aligned(Y));
     StatsF<bf16_t> f{Y, ldy};
     return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
@@ -398,6 +396,7 @@ extern "C" int ddmp_bn_bwd_reduce_bf16(const uint16_t* dZ, int64_t lddz, const u
                                        int C, const float* scale, const float* shift, const float* mean,
                                        const float* rstd, float slope, double* sums2, void* ws, size_t ws_bytes,
                                        ddmp_stream stream) {
+    FinalizeScope fin_scope(sums2, stream);
     ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && lddz >= C && ldy % 8 == 0 && lddz % 8 == 0);
     ARG_TRY(b16_aligned(dZ) && b16_aligned(Y));
@@ -409,7 +408,7 @@ extern "C" int ddmp_bn_bwd_apply_bf16(const uint16_t* dZ, int64_t lddz, const ui
                                       int64_t lddy, int64_t n_rows, int C, const float* scale, const float* shift,
                                       const float* c1, const float* c0, float slope, double* dbias_sums, void* ws,
                                       size_t ws_bytes, ddmp_stream stream) {
-    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0 && dbias_sums);
+    ARG_TRY(dZ && Y && dY && scale && shift && c1 && c0);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16);
     ARG_TRY(ldy >= C && lddz >= C && lddy >= C && ldy % 8 == 0 && lddz % 8 == 0 && lddy % 8 == 0);
     ARG_TRY(b16_aligned(dZ) && b16_aligned(Y) && b16_aligned(dY));
@@ -417,6 +416,12 @@ extern "C" int ddmp_bn_bwd_apply_bf16(const uint16_t* dZ, int64_t lddz, const ui
     const int nblk = colreduce_blocks(n_rows, C, 8);
     const size_t need = ((size_t)nblk * 2 * C + 2 * (size_t)C) * sizeof(double);
     if (!ws || ws_bytes < need) return DDMP_EWORKSPACE;
+    if (!dbias_sums) {
+        hipLaunchKernelGGL((colreduce_kernel<BwdApplyF<bf16_t>>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, f, (int)n_rows,
+                           C, (double*)ws);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     double* tmp = (double*)ws + (size_t)nblk * 2 * C;
     int st = run_colreduce(f, n_rows, C, C, tmp, ws, (size_t)nblk * 2 * C * sizeof(double), (hipStream_t)stream);
     if (st != DDMP_OK) return st;

@@ -1,6 +1,7 @@
 // dtype-tagged entry points (include/ddmp_hip.h, "dtype-tagged forms"): `void*` features + DDMP_F32 | DDMP_BF16.
 // Pure dispatch onto the typed functions; plus the two conversion kernels of the bf16-feature mode.
 #include "b16_common.h"
+#include "finalize.h"
 
 #include <algorithm>
 
@@ -31,6 +32,64 @@ __global__ void ddmp_trace_marker_kernel(int* p) {
 extern "C" int ddmp_trace_marker(ddmp_stream stream) {
     hipLaunchKernelGGL(ddmp_trace_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)nullptr);
     LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+// ---------------------------------------------------------------- tail-fused finalisation of column reductions (finalize.h)
+namespace ddmp {
+static thread_local FinalizeArgs g_fin_pending, g_fin_active;
+FinalizeArgs& finalize_pending() { return g_fin_pending; }
+FinalizeArgs& finalize_active() { return g_fin_active; }
+FinalizeArgs finalize_take(int C) {
+    FinalizeArgs f = g_fin_active;
+    if (f.kind == 0 || f.C != C) return FinalizeArgs();
+    g_fin_active = FinalizeArgs();
+    return f;
+}
+FinalizeScope::FinalizeScope(const double* sums_, ddmp_stream stream) : sums(sums_), st((hipStream_t)stream), owns(false) {
+    if (g_fin_pending.kind != 0) {
+        g_fin_active = g_fin_pending;
+        g_fin_pending = FinalizeArgs();
+        owns = true;
+    }
+}
+FinalizeScope::~FinalizeScope() {
+    if (!owns) return;
+    const FinalizeArgs f = g_fin_active;
+    g_fin_active = FinalizeArgs();
+    if (f.kind == 1)
+        (void)ddmp_bn_prepare_f32(sums, f.n_total, f.C, f.in[0], f.in[1], f.eps, f.momentum, f.out[0], f.out[1], f.out[2],
+                                  f.out[3], f.out[4], f.out[5], (ddmp_stream)st);
+    else if (f.kind == 2)
+        (void)ddmp_bn_bwd_prepare_f32(sums, f.n_total, f.C, f.in[0], f.in[1], f.in[2], f.out[0], f.out[1], f.out[2], f.out[3],
+                                      (ddmp_stream)st);
+}
+}  // namespace ddmp
+
+extern "C" int ddmp_bn_next_prepare(double n_total, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* scale, float* shift, float* mean, float* rstd, float* running_mean,
+                                    float* running_var) {
+    ARG_TRY(n_total > 0 && C > 0 && gamma && beta && scale && shift && mean && rstd);
+    ARG_TRY((running_mean == nullptr) == (running_var == nullptr));
+    ddmp::FinalizeArgs f;
+    f.kind = 1; f.C = C; f.n_total = n_total; f.eps = eps; f.momentum = momentum;
+    f.in[0] = gamma; f.in[1] = beta;
+    f.out[0] = scale; f.out[1] = shift; f.out[2] = mean; f.out[3] = rstd; f.out[4] = running_mean; f.out[5] = running_var;
+    ddmp::finalize_pending() = f;
+    return DDMP_OK;
+}
+extern "C" int ddmp_bn_next_bwd_prepare(double n_total, int C, const float* scale, const float* mean, const float* rstd,
+                                        float* dgamma, float* dbeta, float* c1, float* c0) {
+    ARG_TRY(n_total > 0 && C > 0 && scale && mean && rstd && dgamma && dbeta && c1 && c0);
+    ddmp::FinalizeArgs f;
+    f.kind = 2; f.C = C; f.n_total = n_total;
+    f.in[0] = scale; f.in[1] = mean; f.in[2] = rstd;
+    f.out[0] = dgamma; f.out[1] = dbeta; f.out[2] = c1; f.out[3] = c0;
+    ddmp::finalize_pending() = f;
+    return DDMP_OK;
+}
+extern "C" int ddmp_bn_next_cancel(void) {
+    ddmp::finalize_pending() = ddmp::FinalizeArgs();
     return DDMP_OK;
 }
 
@@ -99,12 +158,14 @@ extern "C" int ddmp_gemm_tn(const void* G, int64_t ldg, const void* Z, int64_t l
 }
 extern "C" int ddmp_bn_stats(const void* Y, int64_t ldy, int64_t n, int C, int dtype, double* sums, void* ws, size_t wsb,
                              ddmp_stream st) {
+    ddmp::FinalizeScope fin_scope(sums, st);
     ARG_TRY(dt_ok(dtype));
     return dtype == DDMP_BF16 ? ddmp_bn_stats_bf16((cb)Y, ldy, n, C, sums, ws, wsb, st) : ddmp_bn_stats_f32((cf)Y, ldy, n, C, sums, ws, wsb, st);
 }
 extern "C" int ddmp_bn_bwd_reduce(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t n, int C, int dtype,
                                   const float* scale, const float* shift, const float* mean, const float* rstd, float slope,
                                   double* sums2, void* ws, size_t wsb, ddmp_stream st) {
+    ddmp::FinalizeScope fin_scope(sums2, st);
     ARG_TRY(dt_ok(dtype));
     return dtype == DDMP_BF16 ? ddmp_bn_bwd_reduce_bf16((cb)dZ, lddz, (cb)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st)
                               : ddmp_bn_bwd_reduce_f32((cf)dZ, lddz, (cf)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st);

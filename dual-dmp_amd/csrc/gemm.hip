@@ -15,6 +15,7 @@
 // blockIdx is XCD-aware: the column tiles of one row panel are adjacent on ONE XCD, so the A panel is
 // fetched from HBM once and re-read from that XCD's L2; W (<= 1 MiB) lives in every L2.
 #include "ddmp_common.h"
+#include "finalize.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -916,6 +917,7 @@ extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* 
                                       const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
                                       void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
                                       ddmp_stream stream) {
+    ddmp::FinalizeScope fin_scope(sums2, stream);
     const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(A && W && out && Yp && scale && shift && mean && rstd && sums2 && n_rows > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ld_out >= K && ldyp >= K);
@@ -1029,6 +1031,7 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
                                       const float* pro_shift, float slope, double* sums2, void* workspace,
                                       size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
                                       ddmp_stream stream) {
+    ddmp::FinalizeScope fin_scope(sums2, stream);
     const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(sums2 && stats_ws);
     if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, M)) return DDMP_EWORKSPACE;

@@ -12,6 +12,7 @@
 //     [x*N/8, (x+1)*N/8), so a row's ~deg re-reads by neighbouring rows hit that XCD's private L2;
 //   * no atomics, fixed summation order -> deterministic.
 #include "ddmp_common.h"
+#include "finalize.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -633,6 +634,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
                                    const float* Yp, int64_t ldyp, const float* scale, const float* shift,
                                    const float* mean, const float* rstd, float slope, double* sums2, void* ws,
                                    size_t ws_bytes, ddmp_stream stream) {
+    ddmp::FinalizeScope fin_scope(sums2, stream);
     ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && C > 0 && ldx >= C && ldy >= C && ldyp >= C);
     ARG_TRY(X != Y);
     if (ws_bytes < ddmp_spmm_bnred_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;

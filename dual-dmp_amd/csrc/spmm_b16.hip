@@ -8,6 +8,7 @@
 // and the accumulation run in float32, the result is rounded to nearest-even once.
 // Algorithmic bytes per call: 2*N*C*2 + 4*nnz + 4*(N+1) + 4*N  (SURVEY.md §8d with s = 2).
 #include "b16_common.h"
+#include "finalize.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -334,6 +335,7 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
                                     const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, float slope, double* sums2, void* ws,
                                     size_t ws_bytes, ddmp_stream stream) {
+    ddmp::FinalizeScope fin_scope(sums2, stream);
     ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && X != Y && shape_ok(X, ldx, Y, ldy, C));
     ARG_TRY(ldyp >= C && ldyp % 8 == 0 && b16_aligned(Yp) && b16_aligned(ws));
     ARG_TRY(coef_ok(scale) && coef_ok(shift) && coef_ok(mean) && coef_ok(rstd));

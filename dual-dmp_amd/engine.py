@@ -230,6 +230,8 @@ class GcnEngine:
         self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
+        self._tail_fused = (isinstance(self.comm, NoComm) and hasattr(ops, "bn_next_prepare")
+                            and os.environ.get("DDMP_TAIL_FUSE", "1") != "0")
         # f16 split GEMM modes: one scale slot per layer and GEMM operand (0: the forward operand X, 1: the gradient
         # operand); the kernels record the operand maxima of this iteration, backward() rolls them into the scales
         # of the next one.  The first iteration measures (prime).
@@ -319,11 +321,17 @@ class GcnEngine:
         self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
         X, pro = self.x0, None
         halo_started = False
+        # one device: the coefficients ride on the second stage of the reduction that produces the sums (finalize.h);
+        # across devices the sums are all-reduced first
+        tail = self._tail_fused and not use_running
         for l in range(12):
             i = l + 1
             W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
             b = L.view(params, "conv%d.bias" % i)
             Y = self.Y[l]
+            if tail:
+                ops.bn_next_prepare(self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i), self.bn4[l],
+                                    running=(self.running[l][0], self.running[l][1]) if update_running else None)
             if self.agg_first[l]:
                 P = self.P[l]
                 if l > 0 or not self._p1_ready:
@@ -356,7 +364,7 @@ class GcnEngine:
                 yield _Both(h_stats, h_halo)
             if use_running:
                 self._bn4_from_running(l, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i))
-            else:
+            elif not tail:
                 ops.bn_prepare(self.sums, self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i),
                                self.bn4[l], running=(self.running[l][0], self.running[l][1]) if update_running else None)
             X, pro = Y, (self.bn4[l][0], self.bn4[l][1])
@@ -416,6 +424,17 @@ class GcnEngine:
         kz, dZ = take(32)
         if self.perm is not None:
             dout = dout.index_select(0, self.perm)
+        tail = self._tail_fused
+
+        def arm(l):
+            """Layer l's BatchNorm-backward coefficients come with the reduction launched next (one device)."""
+            if tail:
+                ops.bn_next_bwd_prepare(self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % (l + 1)),
+                                        L.view(grads, "bn%d.bias" % (l + 1)), self.c10s[l])
+
+        # the conv-bias gradients: zero after BatchNorm in exact arithmetic (its backward output has zero column mean), where
+        # the reference's autograd leaves float32 summation noise.  Written as 0 on every route, in one launch
+        torch._foreach_zero_([L.view(grads, "conv%d.bias" % (l + 1)) for l in range(12)])
         ops.head_bwd(self.Y[11], self.bn4[11], L.view(params, "linear1.weight"), L.view(params, "linear1.bias"),
                      L.view(params, "linear2.weight"), L.view(params, "linear2.bias"), self.kind, dout.contiguous(), dZ,
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
@@ -429,22 +448,26 @@ class GcnEngine:
         def spmm_to_dz(src, dst, l):
             """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""
             if fuse_red and l > 0:
+                arm(l - 1)
                 ops.spmm_bnred(g, src, dst[:n], self.Y[l - 1], self.bn4[l - 1], self.sums)
                 return True
             ops.spmm(g, src, out=dst[:n])
             return False
 
-        # OFF by default: measured at 1M faces (round 3, interleaved A/B): the fused dgrads cost +2.4 ms per step for the 1.56 ms
-        # of bn_bwd_reduce passes they replace (step 48.7 -> 49.6 ms) -- 128 strided loads of Yp and 256 float64 FMAs per lane
-        # and tile in the epilogue of a kernel that already runs against the socket power cap.  DDMP_GEMM_BNRED=1 for A/B.
+        # transform-first dgrads with the next BatchNorm-backward reductions in their epilogue (row-register kernel, float32).
+        # Measured at 1M faces (interleaved A/B, 10 steps each): 47.49 / 47.35 ms with, 47.75 / 47.78 ms without.  (A first
+        # version lost 0.9 ms: the 32 per-column coefficients of the epilogue were hoisted out of the tile loop as invariants and
+        # SPILLED the main loop -- scratch reloads inside the counted-vmcnt pipeline; they now live in LDS and
+        # scripts/check_rr_asm.py audits that form too.)  DDMP_GEMM_BNRED=0 for A/B.
         fuse_dgrad_red = (getattr(ops, "gemm_nn_bnred_supported", None) is not None and isinstance(self.comm, NoComm)
-                          and os.environ.get("DDMP_GEMM_BNRED", "0") == "1")
+                          and os.environ.get("DDMP_GEMM_BNRED", "1") != "0")
 
         def dgrad_to_dz(dH, W, dZ, l):
             """dZ of layer l-1 = dH . W (transform-first layer l > 0); with that layer's BatchNorm-backward column reductions
             from the GEMM epilogue where the kernel exists (one device: across devices the sums are all-reduced anyway, but
             the halo rows of dZ are not this rank's to count -- the epilogue sums owned rows only, which is what n selects)."""
             if fuse_dgrad_red and ops.gemm_nn_bnred_supported(L.cout[l], L.cin_p[l], n, self.dtype):
+                arm(l - 1)
                 ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n)
                 return True
             ops.gemm_nn(dH, W, out=dZ, n_rows=n)
@@ -457,16 +480,15 @@ class GcnEngine:
             dW = L.view(grads, "conv%d.lin.weight" % i, true_shape=False)
             Y, bn4, c10 = self.Y[l], self.bn4[l], self.c10s[l]
             if not have_sums:                                    # else: produced by the SpMM that wrote dZ
+                arm(l)
                 ops.bn_bwd_reduce(dZ, Y, bn4, sums2=self.sums, n_rows=n)
             have_sums = False
             yield comm.start_all_reduce(self.sums[: 2 * co])
-            ops.bn_bwd_prepare(self.sums, self.n_total, bn4, L.view(grads, "bn%d.weight" % i),
-                               L.view(grads, "bn%d.bias" % i), c10)
+            if not tail:
+                ops.bn_bwd_prepare(self.sums, self.n_total, bn4, L.view(grads, "bn%d.weight" % i),
+                                   L.view(grads, "bn%d.bias" % i), c10)
             if self.fuse_bnbwd[l]:
-                # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads.
-                # Its column sums (the conv-bias gradient) are exactly zero in exact arithmetic -- BatchNorm's backward
-                # output has zero column mean -- where the reference's autograd leaves float32 summation noise.
-                L.view(grads, "conv%d.bias" % i).zero_()
+                # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads
                 kp, dP = take(ci)
                 self._scales(l, 1)
                 ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n)
@@ -481,7 +503,6 @@ class GcnEngine:
                 continue
             if self.fuse_gather_bwd[l]:
                 # transform-first layer on one device: dY is rebuilt by the SpMM on its gather of (dZ, Y) rows
-                L.view(grads, "conv%d.bias" % i).zero_()        # (exactly zero, as in the fused GEMM form above)
                 kh, dH = take(co)
                 ops.spmm_bnbwd(g, dZ, Y, bn4, c10, dH[:n])
                 release(kz)
@@ -493,9 +514,8 @@ class GcnEngine:
                 release(kh)
                 continue
             ky, dY = take(co)
-            ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, self.sums, n_rows=n)
+            ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, None, n_rows=n)
             release(kz)                                          # dZ is dead once dY exists
-            ops.f64_to_f32(self.sums[:co], L.view(grads, "conv%d.bias" % i))
             if l > 0:
                 Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
             else:

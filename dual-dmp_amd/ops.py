@@ -593,6 +593,23 @@ def bn_prepare(sums, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momen
     return out4
 
 
+def bn_next_prepare(n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+    """Arm the NEXT statistics-producing call of this thread (bn_stats / gemm_nt_stats) so that its second stage writes
+    what bn_prepare would (ddmp_bn_next_prepare: one launch less, bitwise the same coefficients)."""
+    C = gamma.numel()
+    rm, rv = (None, None) if running is None else running
+    check(_lib.lib().ddmp_bn_next_prepare(float(n_total), C, _p(gamma), _p(beta), eps, momentum, _p(out4[0]), _p(out4[1]),
+                                          _p(out4[2]), _p(out4[3]), _p(rm), _p(rv)), "ddmp_bn_next_prepare")
+
+
+def bn_next_bwd_prepare(n_total, bn4, dgamma, dbeta, c10):
+    """Arm the NEXT call that produces the BatchNorm-backward reductions (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred) so
+    that its second stage writes what bn_bwd_prepare would."""
+    C = dgamma.numel()
+    check(_lib.lib().ddmp_bn_next_bwd_prepare(float(n_total), C, _p(bn4[0]), _p(bn4[2]), _p(bn4[3]), _p(dgamma), _p(dbeta),
+                                              _p(c10[0]), _p(c10[1])), "ddmp_bn_next_bwd_prepare")
+
+
 def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):
     y, ldy = _mat(y, "y")
     if out is None:
@@ -628,6 +645,7 @@ def bn_bwd_prepare(sums2, n_total, bn4, dgamma, dbeta, c10):
 
 
 def bn_bwd_apply(dz, y, bn4, c10, dy, dbias_sums, slope=SLOPE, n_rows=None):
+    """dy = BatchNorm+LeakyReLU backward of (dz, y); dbias_sums (float64 [C]): its column sums, None: not computed."""
     dz, lddz = _mat(dz, "dz")
     y, ldy = _mat(y, "y", dz)
     dy, lddy = _mat(dy, "dy", dz)

@@ -145,7 +145,19 @@ int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float* Y, int64_
 int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const float* scale, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, float* c1, float* c0,
                             ddmp_stream stream);
-/* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias) */
+/* Tail-fused coefficients (round 3): arm the NEXT call on this host thread that produces a float64 [2C] column reduction
+ * (ddmp_bn_stats*, ddmp_gemm_nt_stats_*, ddmp_bn_bwd_reduce*, ddmp_spmm_bnred*, ddmp_gemm_nn_bnred_f32) so that the second
+ * stage of that reduction ALSO writes what ddmp_bn_prepare_f32 / ddmp_bn_bwd_prepare_f32 would (same arithmetic, bitwise the
+ * same values; the sums are still written) -- one launch less per BatchNorm and direction.  C must be the reduction's width.
+ * No device work, no stream: the arguments are remembered until that call; ddmp_bn_next_cancel drops them. */
+int ddmp_bn_next_prepare(double n_total, int C, const float* gamma, const float* beta, float eps, float momentum,
+                         float* scale, float* shift, float* mean, float* rstd, float* running_mean /*nullable*/,
+                         float* running_var /*nullable*/);
+int ddmp_bn_next_bwd_prepare(double n_total, int C, const float* scale, const float* mean, const float* rstd,
+                             float* dgamma, float* dbeta, float* c1, float* c0);
+int ddmp_bn_next_cancel(void);
+/* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias; dbias_sums NULL: dY only -- behind
+ * a BatchNorm those sums are zero in exact arithmetic) */
 int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, float* dY, int64_t lddy,
                           int64_t n_rows, int C, const float* scale, const float* shift, const float* c1,
                           const float* c0, float slope, double* dbias_sums /*[C]*/, void* workspace,

@@ -19,7 +19,7 @@ lines = open(asm).read().split("\n")
 
 
 def audit(name, body):
-    m = re.search(r"gemm_rr_kernelILi(\d)ELb(\d)ELi(\d)E", name)
+    m = re.search(r"gemm_rr_kernelILi(\d)EL[bi](\d)ELi(\d)E", name)
     pm, stats, nb = int(m.group(1)), int(m.group(2)), int(m.group(3))
     na = 4 if pm == 2 else 2
     nv = 4 + na

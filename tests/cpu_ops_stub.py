@@ -148,7 +148,8 @@ def bn_bwd_apply(dz, y, bn4, c10, dy, dbias_sums, slope=SLOPE, n_rows=None):
     g = _g(dz[:n], y[:n], bn4, slope)
     o = bn4[0].double() * g + c10[0].double() * y[:n].double() + c10[1].double()
     dy[:n].copy_(o)
-    dbias_sums[:C].copy_(o.sum(0))
+    if dbias_sums is not None:
+        dbias_sums[:C].copy_(o.sum(0))
     return dy
 
 

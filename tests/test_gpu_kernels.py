@@ -272,7 +272,7 @@ def test_gemm_nn_with_bn_backward_reductions(dev, n, M, K):
     assert torch.equal(out, ops.gemm_nn(dhg, wg))                                   # the same kernel without the epilogue
     sums_pass = torch.zeros(2 * K, dtype=torch.float64, device=dev)
     ops.bn_bwd_reduce(out, ypg, bn4g, sums2=sums_pass)
-    assert relerr(sums, sums_pass) < 1e-9, relerr(sums, sums_pass)                  # float64 sums of the same float32 terms
+    assert relerr(sums, sums_pass) < 2e-6, relerr(sums, sums_pass)                  # float32 over 16 rows, float64 from there on
     a, b, mu, rs = (bn4[i].double() for i in range(4))
     g = out.double().cpu() * torch.where(yp.double() * a + b > 0, 1.0, 0.01)
     ref_s = torch.cat([g.sum(0), (g * (yp.double() - mu) * rs).sum(0)])
@@ -521,6 +521,76 @@ def test_batchnorm_lrelu_forward_backward(dev, n, C):
     # conv-bias gradient = column sums of dY: analytically zero after BN
     assert float(dbs[:C].abs().max()) < 1e-3 * float(yd.grad.abs().sum(0).max())
     assert relerr(ops.colsum(dz.to(dev)), dz.double().sum(0)) < 1e-7
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,C", [(1500, 32), (13068, 512), (70001, 256)])
+def test_tail_fused_coefficients_are_bitwise_those_of_the_prepare_kernels(dev, graphs, n, C, dtype):
+    """ddmp_bn_next_prepare / ddmp_bn_next_bwd_prepare: the second stage of the armed reduction writes the BatchNorm
+    coefficients itself (finalize.h) -- same sums, same coefficients, same running statistics, on every reducing entry;
+    an armed call whose route has no second stage launches the stand-alone kernel by itself."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n + C)
+    y = (torch.randn(n, C, device=dev) * 2 + 1).to(dtype)
+    dz = torch.randn(n, C, device=dev).to(dtype)
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+
+    def coeffs(armed, stats):
+        bn4 = torch.zeros(4, C, device=dev)
+        run = torch.stack([torch.full((C,), 0.25), torch.full((C,), 2.0)]).to(dev)
+        if armed:
+            ops.bn_next_prepare(n, gamma, beta, bn4, running=(run[0], run[1]))
+        sums = stats()
+        if not armed:
+            ops.bn_prepare(sums, n, gamma, beta, bn4, running=(run[0], run[1]))
+        return sums.clone(), bn4, run
+
+    ref = coeffs(False, lambda: ops.bn_stats(y))
+    got = coeffs(True, lambda: ops.bn_stats(y))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    bn4 = ref[1]
+    if C >= 64:                                               # statistics from the GEMM epilogue (or GEMM + pass): both routes
+        K = 64
+        a_ = torch.randn(n, K, device=dev).to(dtype)
+        w_ = torch.randn(C, K, device=dev) / 8
+        out = torch.empty(n, C, device=dev, dtype=dtype)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        r2 = coeffs(False, lambda: (ops.gemm_nt_stats(a_, w_, sums, out=out), sums)[1])
+        g2 = coeffs(True, lambda: (ops.gemm_nt_stats(a_, w_, sums, out=out), sums)[1])
+        for a, b in zip(r2, g2):
+            assert torch.equal(a, b)
+
+    def bwd(armed, red):
+        dgamma, dbeta, c10 = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2, C, device=dev)
+        if armed:
+            ops.bn_next_bwd_prepare(n, bn4, dgamma, dbeta, c10)
+        sums2 = red()
+        if not armed:
+            ops.bn_bwd_prepare(sums2, n, bn4, dgamma, dbeta, c10)
+        return sums2.clone(), dgamma, dbeta, c10
+
+    for a, b in zip(bwd(False, lambda: ops.bn_bwd_reduce(dz, y, bn4)), bwd(True, lambda: ops.bn_bwd_reduce(dz, y, bn4))):
+        assert torch.equal(a, b)
+    if n == 1500:                                             # the reductions from the gather's epilogue
+        ei, ng = graphs["ico3_f"]
+        g = ops.graph_for(ei.to(dev), ng)
+        x, yp, o = dz[:ng].contiguous(), y[:ng].contiguous(), torch.empty(ng, C, device=dev, dtype=dtype)
+        s2 = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        for a, b in zip(bwd(False, lambda: (ops.spmm_bnred(g, x, o, yp, bn4, s2), s2)[1]),
+                        bwd(True, lambda: (ops.spmm_bnred(g, x, o, yp, bn4, s2), s2)[1])):
+            assert torch.equal(a, b)
+    # a non-reducing call in between leaves the request armed for the reduction that follows
+    dgamma, dbeta, c10 = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2, C, device=dev)
+    ops.bn_next_bwd_prepare(n, bn4, dgamma, dbeta, c10)
+    ops.bn_lrelu_apply(y, bn4[0], bn4[1])
+    ops.bn_bwd_reduce(dz, y, bn4)
+    assert torch.equal(c10, bwd(False, lambda: ops.bn_bwd_reduce(dz, y, bn4))[3])
+    # dY without its (analytically zero) column sums
+    dy0, dy1 = torch.empty_like(y), torch.empty_like(y)
+    ops.bn_bwd_apply(dz, y, bn4, c10, dy0, torch.empty(2 * C, dtype=torch.float64, device=dev))
+    ops.bn_bwd_apply(dz, y, bn4, c10, dy1, None)
+    assert torch.equal(dy0, dy1)
 
 
 @pytest.mark.parametrize("kind", [0, 1])

@@ -335,6 +335,7 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect
             assert eng.n_rows >= 65536
             assert sum(eng.fuse_bnbwd) >= 4 and sum(eng.fuse_gather_bwd) >= 3, (eng.fuse_bnbwd, eng.fuse_gather_bwd)
             assert ops.gemm_bnbwd_supported(512, 256, eng.n_rows) and ops.get_gemm_mode() == 13
+            assert ops.gemm_nn_bnred_supported(256, 512, eng.n_rows) and eng._tail_fused
     for it in range(1, iters + 1):
         if it in check_at:
             for which, (net, ref, opt) in enumerate(((posnet, rp, op), (normnet, rn, on))):
@@ -449,6 +450,30 @@ def test_graph_replay_is_bit_identical_to_eager(dev):
         for x, y in zip(a[1:], b[1:]):
             assert torch.equal(x, y), key
     assert a[5][3] > 0                                     # the gate did open
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tail_fused_finalisation_is_bit_identical(dev, monkeypatch, dtype):
+    """Round 3: BatchNorm coefficients written by the second stage of the reduction that produced their sums
+    (DDMP_TAIL_FUSE, default on) against the stand-alone prepare kernels: the same iteration bit for bit."""
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    gt, noisy, smooth, data = _case(dev, "grid")
+    runs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DDMP_TAIL_FUSE", flag)
+        torch.manual_seed(5)
+        posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=2)
+        losses = [tr.step().item() for _ in range(4)]
+        assert posnet._engine._tail_fused == (flag == "1")
+        runs.append((losses, tr.pos.clone(), tr.norm.clone(), posnet.arena.data.clone(), normnet.arena.data.clone(),
+                     [r.clone() for r in normnet._engine.running]))
+    assert runs[0][0] == runs[1][0]
+    for x, y in zip(runs[0][1:5], runs[1][1:5]):
+        assert torch.equal(x, y)
+    for x, y in zip(runs[0][5], runs[1][5]):
+        assert torch.equal(x, y)
 
 
 def test_reference_loop_shape_on_our_modules(dev, oracle):
