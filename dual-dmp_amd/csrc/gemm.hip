@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -411,6 +412,80 @@ static bool ws_enabled() {
     return e == 1;
 }
 
+// ---------------------------------------------------------------- weights prepared once per iteration (round 3)
+// Every GEMM call used to split its weight matrix into 16-bit planes itself: absolute maximum (memset + kernel) + split
+// kernel, ~90 launches of 4-10 us per training iteration.  ddmp_gemm_prepare_weights does all matrices of a net in TWO
+// launches into caller-owned plane buffers; a GEMM call whose workspace IS such a buffer and that was announced with
+// ddmp_gemm_next_prepared() skips its own split -- if and only if the recorded layout is exactly the one its route wants
+// (same matrix, shape, orientation, plane format); otherwise it splits as before.  Same device code, same values.
+enum { kWPanelF16 = 1, kWPanelB16 = 2, kWTiled = 3, kWPlain = 4 };
+struct WPrepDesc {
+    const float* W;
+    void* planes;
+    int64_t ldw;
+    int kind, nterm, MD, KD, transpose, P;                       // P: MP (panel kinds) | BN (tiled) | 0
+};
+constexpr int kWPrepMax = 24;
+struct WPrepBatch {
+    int n;
+    WPrepDesc d[kWPrepMax];
+};
+static inline bool wprep_same(const WPrepDesc& a, const WPrepDesc& b) {
+    return a.W == b.W && a.planes == b.planes && a.ldw == b.ldw && a.kind == b.kind && a.nterm == b.nterm && a.MD == b.MD &&
+           a.KD == b.KD && a.transpose == b.transpose && a.P == b.P;
+}
+static thread_local std::vector<WPrepDesc> g_w_registry;         // what the last ddmp_gemm_prepare_weights calls wrote
+static thread_local bool g_w_next_prepared = false, g_w_call_prepared = false;
+// at a split site: does `planes` already hold exactly this layout (and did the caller say so)?
+static bool w_prepared(const float* W, int64_t ldw, void* planes, int kind, int nterm, int MD, int KD, int transpose, int P) {
+    if (!g_w_call_prepared) return false;
+    const WPrepDesc want{W, planes, ldw, kind, nterm, MD, KD, transpose, P};
+    for (const WPrepDesc& e : g_w_registry)
+        if (wprep_same(e, want)) return true;
+    return false;
+}
+
+// per f16 matrix: 8 partial absolute maxima (no atomics, no zeroing)
+__global__ __launch_bounds__(256) void wprep_max_kernel(WPrepBatch b, float* __restrict__ scratch) {
+    const WPrepDesc d = b.d[blockIdx.y];
+    if (d.kind != kWPanelF16) return;
+    const int rows = d.transpose ? d.KD : d.MD, cols = d.transpose ? d.MD : d.KD;     // W as stored: [rows][cols]
+    float m = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(d.W[(int64_t)r * d.ldw + c]));
+    m = f16s_wave_max(m);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        if (!(m <= 3.0e38f)) m = 3.0e38f;
+        scratch[blockIdx.y * 8 + blockIdx.x] = m;
+    }
+}
+__global__ __launch_bounds__(256) void wprep_split_kernel(WPrepBatch b, const float* __restrict__ scratch) {
+    const WPrepDesc d = b.d[blockIdx.y];
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    if (d.kind == kWPanelF16) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, scratch[blockIdx.y * 8 + j]);
+        float* wscale = (float*)((char*)d.planes + (size_t)2 * d.P * d.KD * 2);      // behind the planes (launch_panel)
+        if (bid == 0 && threadIdx.x == 0) *wscale = m;
+        split_w_panel_body<2, _Float16>(d.W, d.ldw, d.MD, d.KD, d.transpose, d.P, (_Float16*)d.planes,
+                                        f16s_scale(m, kF16TargetExact), bid, nblk);
+    } else if (d.kind == kWPanelB16) {
+        if (d.nterm == 3) split_w_panel_body<3, __bf16>(d.W, d.ldw, d.MD, d.KD, d.transpose, d.P, (__bf16*)d.planes, 1.f, bid, nblk);
+        else split_w_panel_body<2, __bf16>(d.W, d.ldw, d.MD, d.KD, d.transpose, d.P, (__bf16*)d.planes, 1.f, bid, nblk);
+    } else if (d.kind == kWTiled) {
+        if (d.nterm == 3) split_w_tiled_body<3>(d.W, d.ldw, d.MD, d.KD, d.transpose, d.P, (__bf16*)d.planes, bid, nblk);
+        else split_w_tiled_body<2>(d.W, d.ldw, d.MD, d.KD, d.transpose, d.P, (__bf16*)d.planes, bid, nblk);
+    } else if (d.kind == kWPlain) {
+        if (d.nterm == 3) split_w_body<3>(d.W, d.ldw, d.MD, d.KD, d.transpose, (__bf16*)d.planes, bid, nblk);
+        else split_w_body<2>(d.W, d.ldw, d.MD, d.KD, d.transpose, (__bf16*)d.planes, bid, nblk);
+    }
+}
+
 // persistent wave-specialised kernel: pre-split W planes [MD][KD], reduction length KD % 32 == 0, KD >= 96
 template <bool PRO>
 static void launch_ws(int mode, const float* A, int64_t lda, const float* W, int64_t ldw, int transpose, void* planes,
@@ -422,7 +497,8 @@ static void launch_ws(int mode, const float* A, int64_t lda, const float* W, int
         const int BN = 64 * TN;
         const int64_t total = ddmp::cdiv(MD, BN) * BN * (int64_t)KD;
         const int sgrid = (int)std::min<int64_t>(ddmp::cdiv(total, 256), 1024);
-        if (mode == 6)
+        if (w_prepared(W, ldw, planes, kWTiled, mode == 6 ? 3 : 2, MD, KD, transpose, BN)) {
+        } else if (mode == 6)
             hipLaunchKernelGGL((split_w_tiled_kernel<3>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, BN, (__bf16*)planes);
         else
             hipLaunchKernelGGL((split_w_tiled_kernel<2>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, BN, (__bf16*)planes);
@@ -491,9 +567,11 @@ struct ScaleCtx {
     int prime = 0;
 };
 static thread_local ScaleCtx g_scale_ctx;
-static ScaleCtx take_scale_ctx() {
+static ScaleCtx take_scale_ctx() {                               // (top of every GEMM entry point)
     ScaleCtx c = g_scale_ctx;
     g_scale_ctx = ScaleCtx();
+    g_w_call_prepared = g_w_next_prepared;
+    g_w_next_prepared = false;
     return c;
 }
 // slot[0] = max |f(A)|, exactly (pre-pass)
@@ -530,16 +608,20 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         float* wscale = (float*)tail;
         float* slot = ctx.a ? ctx.a : (float*)(tail + 16);
         const bool prime = !ctx.a || ctx.prime;
-        (void)hipMemsetAsync(wscale, 0, 4, st);                   // = max |W| (the kernels derive the power of two)
-        hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
-                           transpose ? KD : MD, transpose ? MD : KD, wscale);
+        const bool w_ready = w_prepared(W, ldw, planes, kWPanelF16, 2, MD, KD, transpose, MP);
+        if (!w_ready) {
+            (void)hipMemsetAsync(wscale, 0, 4, st);               // = max |W| (the kernels derive the power of two)
+            hipLaunchKernelGGL(f16s_wmax_kernel, dim3((unsigned)std::min(transpose ? KD : MD, 128)), dim3(256), 0, st, W, ldw,
+                               transpose ? KD : MD, transpose ? MD : KD, wscale);
+        }
         // PM = 2 with two column halves (512 <- 512 dgrad): the halves are separate, freely drifting workgroups and BOTH stream
         // (dZ, Y) -- PMC: the family read 27.3 GB per step for 18.4 GB algorithmic, the second half's rows mostly missing the
         // XCD's L2 -- while the row-panel kernel reads them once at the same speed (1499 vs 1490-1511 us): that shape keeps it.
         static const bool rr_pm2_wide = env_rows("DDMP_RR_PM2_WIDE", 0) == 1;
         const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0) && !(PM == 2 && MD > kRRCols && !rr_pm2_wide);
-        hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
-                           (_Float16*)planes, (const float*)wscale);
+        if (!w_ready)
+            hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
+                               (_Float16*)planes, (const float*)wscale);
         if (prime) f16s_measure<PM>(A, lda, A2, lda2, n_rows, KD, ps, psh, pc1, pc0, slope, slot, st);
         const int target = prime ? kF16TargetExact : kF16TargetStale;
         const void* Bh = planes;
@@ -590,7 +672,8 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         }
         return;
     }
-    if (mode == 6)
+    if (w_prepared(W, ldw, planes, kWPanelB16, mode == 6 ? 3 : 2, MD, KD, transpose, MP)) {
+    } else if (mode == 6)
         hipLaunchKernelGGL((split_w_panel_kernel<3, __bf16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes, (const float*)nullptr);
     else
         hipLaunchKernelGGL((split_w_panel_kernel<2, __bf16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP, (__bf16*)planes, (const float*)nullptr);
@@ -679,11 +762,85 @@ static bool presplit_w(const float* W, int64_t ldw, int M, int K, int transpose,
         (reinterpret_cast<uintptr_t>(ws) & 15))
         return false;
     const int grid = (int)std::min<int64_t>(cdiv((int64_t)M * K, 256), 1024);
+    if (w_prepared(W, ldw, ws, kWPlain, mode == 6 ? 3 : 2, M, K, transpose, 0)) return true;
     if (mode == 6)
         hipLaunchKernelGGL((split_w_kernel<3>), dim3(grid), dim3(256), 0, st, W, ldw, M, K, transpose, (__bf16*)ws);
     else
         hipLaunchKernelGGL((split_w_kernel<2>), dim3(grid), dim3(256), 0, st, W, ldw, M, K, transpose, (__bf16*)ws);
     return hipGetLastError() == hipSuccess;
+}
+
+// The plane layout the entry points below will want for W [M,K] in the forward (form 0: Y[n,M] = f(A[n,K]) . W^T) or dgrad
+// (form 1: Y[n,K] = A[n,M] . W) product over n_rows rows -- the same tests, in the same order, as those entry points
+// (which stay the ground truth: a layout they do not want is simply ignored and re-made).
+static WPrepDesc plan_w(int form, int64_t n_rows, const float* W, int64_t ldw, int M, int K, int has_pro, void* planes,
+                        size_t planes_bytes) {
+    WPrepDesc d{W, planes, ldw, 0, 0, 0, 0, 0, 0};
+    const int mode = gemm_mode();
+    if (mode == 0 || !planes || (reinterpret_cast<uintptr_t>(planes) & 15) || planes_bytes < ddmp_gemm_rows_workspace_bytes(K, M))
+        return d;
+    const int KD = form ? M : K, MD = form ? K : M;              // reduction length / output width
+    d.transpose = form ? 1 : 0;
+    d.nterm = mode == 6 ? 3 : 2;
+    float dummy;
+    if (!(has_pro && KD > 512) && panel_ok(KD, MD, &dummy, MD, planes, planes_bytes, n_rows)) {
+        const int WC = MD > 256 ? 4 : MD > 128 ? 2 : 1;
+        const int NJ = MD > 128 ? 4 : MD > 64 ? 4 : MD > 32 ? 2 : 1;
+        d.P = 32 * NJ * WC;
+        d.MD = MD;
+        d.KD = KD;
+        if (mode == 6 && WC > 1 && gemm_f16()) {
+            d.kind = kWPanelF16;
+            d.nterm = 2;
+        } else {
+            d.kind = kWPanelB16;
+        }
+        return d;
+    }
+    if (ws_ok(KD, MD, (const float*)nullptr, 4, planes, planes_bytes)) {
+        d.kind = kWTiled;
+        d.MD = MD;
+        d.KD = KD;
+        d.P = 64 * (MD > 64 ? 2 : 1);
+        return d;
+    }
+    if (KD % 8 == 0) {                                           // presplit_w(W, ldw, M, K, transpose, ...)
+        d.kind = kWPlain;
+        d.MD = M;
+        d.KD = K;
+    }
+    return d;
+}
+
+extern "C" int ddmp_gemm_next_prepared(void) {
+    g_w_next_prepared = true;
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, const int* M, const int* K,
+                                         const int* form, const int* has_pro, void* const* planes, const size_t* planes_bytes,
+                                         int64_t n_rows, float* scratch, ddmp_stream stream) {
+    ARG_TRY(n > 0 && n <= kWPrepMax && W && ldw && M && K && form && planes && planes_bytes && scratch && n_rows > 0);
+    WPrepBatch b;
+    b.n = 0;
+    bool any_f16 = false;
+    for (int i = 0; i < n; ++i) {
+        ARG_TRY(W[i] && M[i] > 0 && K[i] > 0 && ldw[i] >= K[i] && aligned16(W[i]) && ldw[i] % 4 == 0);
+        const WPrepDesc d = plan_w(form[i], n_rows, W[i], ldw[i], M[i], K[i], has_pro ? has_pro[i] : 0, planes[i], planes_bytes[i]);
+        // whatever was recorded for this buffer is overwritten (or no longer maintained) from here on
+        for (size_t e = 0; e < g_w_registry.size();)
+            if (g_w_registry[e].planes == planes[i]) g_w_registry.erase(g_w_registry.begin() + e); else ++e;
+        if (d.kind == 0) continue;
+        any_f16 |= d.kind == kWPanelF16;
+        b.d[b.n++] = d;
+    }
+    if (b.n == 0) return DDMP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (any_f16) hipLaunchKernelGGL(wprep_max_kernel, dim3(8, (unsigned)b.n), dim3(256), 0, st, b, scratch);
+    hipLaunchKernelGGL(wprep_split_kernel, dim3(32, (unsigned)b.n), dim3(256), 0, st, b, (const float*)scratch);
+    LAUNCH_TRY();
+    for (int i = 0; i < b.n; ++i) g_w_registry.push_back(b.d[i]);
+    return DDMP_OK;
 }
 
 extern "C" int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y,
@@ -1047,6 +1204,7 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
         return DDMP_OK;
     }
     g_scale_ctx = ctx;
+    g_w_next_prepared = g_w_call_prepared;
     int rc = ddmp_gemm_nt_f32(A, lda, W, ldw, Y, ldy, n_rows, K, M, bias, pro_scale, pro_shift, slope, workspace,
                               workspace_bytes, stream);
     if (rc != DDMP_OK) return rc;

@@ -230,6 +230,10 @@ class GcnEngine:
         self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
+        # weights split into their 16-bit planes once per iteration, all layers in two launches (float32 features)
+        self._wplanes = None
+        self._prep_weights = (dtype == torch.float32 and hasattr(ops, "gemm_prepare_weights")
+                              and os.environ.get("DDMP_PREP_WEIGHTS", "1") != "0")
         self._tail_fused = (isinstance(self.comm, NoComm) and hasattr(ops, "bn_next_prepare")
                             and os.environ.get("DDMP_TAIL_FUSE", "1") != "0")
         # f16 split GEMM modes: one scale slot per layer and GEMM operand (0: the forward operand X, 1: the gradient
@@ -311,6 +315,26 @@ class GcnEngine:
         b[2] = rm
         b[3] = rstd
 
+    def _prepare_weights(self, params: torch.Tensor):
+        """Plane buffers per (layer, forward | dgrad) and the batched split of this iteration's weights into them."""
+        if not self._prep_weights:
+            return
+        L = self.layout
+        if self._wplanes is None:
+            need = ops.gemm_rows_workspace_bytes
+            self._wplanes = {(l, form): torch.empty(need(L.cin_p[l], L.cout[l]), dtype=torch.uint8, device=self.device)
+                             for l in range(12) for form in (0, 1) if not (form == 1 and l == 0)}
+            self._wscratch = torch.empty(8 * len(self._wplanes), dtype=torch.float32, device=self.device)
+        items = []
+        for (l, form), buf in self._wplanes.items():
+            W = L.view(params, "conv%d.lin.weight" % (l + 1), true_shape=False)
+            items.append((W, form, form == 0 and not self.agg_first[l] and l > 0, buf))
+        ops.gemm_prepare_weights(items, self.n_rows, self._wscratch)
+
+    def _wp(self, l, form):
+        """Keyword for the GEMM call of layer l (form 0 forward, 1 dgrad): its prepared planes, if any."""
+        return {} if self._wplanes is None else {"wplanes": self._wplanes[(l, form)]}
+
     def forward_steps(self, params: torch.Tensor, update_running: bool = True, use_running: bool = False):
         """The forward pass as a generator that yields at every collective it STARTS (halo exchange, BatchNorm
         statistics all-reduce): the caller waits on the handle before resuming.  A multi-device trainer runs the
@@ -319,6 +343,7 @@ class GcnEngine:
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         self.n_forward = getattr(self, "n_forward", 0) + 1        # (dist: cache key of the all-gathered outputs)
         self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
+        self._prepare_weights(params)
         X, pro = self.x0, None
         halo_started = False
         # one device: the coefficients ride on the second stage of the reduction that produces the sums (finalize.h);
@@ -341,14 +366,14 @@ class GcnEngine:
                     self._p1_ready = True
                 self._scales(l, 0)
                 if hasattr(ops, "gemm_nt_stats"):                # BatchNorm statistics from the GEMM epilogue
-                    ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n)
+                    ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n, **self._wp(l, 0))
                 else:
                     ops.gemm_nt(P, W, out=Y, bias=b, n_rows=n)
                     ops.bn_stats(Y, sums=self.sums, n_rows=n)
             else:
                 H = self._work(0, L.cout[l])
                 self._scales(l, 0)
-                ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n)
+                ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0))
                 yield comm.start_halo(H, n)
                 ops.spmm(g, H, out=Y[:n], bias=b)
                 ops.bn_stats(Y, sums=self.sums, n_rows=n)
@@ -468,9 +493,9 @@ class GcnEngine:
             the halo rows of dZ are not this rank's to count -- the epilogue sums owned rows only, which is what n selects)."""
             if fuse_dgrad_red and ops.gemm_nn_bnred_supported(L.cout[l], L.cin_p[l], n, self.dtype):
                 arm(l - 1)
-                ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n)
+                ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n, **self._wp(l, 1))
                 return True
-            ops.gemm_nn(dH, W, out=dZ, n_rows=n)
+            ops.gemm_nn(dH, W, out=dZ, n_rows=n, **self._wp(l, 1))
             return False
 
         for l in range(11, -1, -1):
@@ -491,7 +516,7 @@ class GcnEngine:
                 # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads
                 kp, dP = take(ci)
                 self._scales(l, 1)
-                ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n)
+                ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n, **self._wp(l, 1))
                 # after the dgrad GEMM: two panel GEMMs cannot share a CU (LDS), the wgrad's partners are the SpMM and
                 # the BatchNorm passes that follow
                 wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n), kz)
@@ -524,7 +549,7 @@ class GcnEngine:
                 if l > 0:
                     kp, dP = take(ci)
                     self._scales(l, 1)
-                    ops.gemm_nn(dY, W, out=dP, n_rows=n)
+                    ops.gemm_nn(dY, W, out=dP, n_rows=n, **self._wp(l, 1))
                 wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n), ky)
                 if l > 0:
                     release(ky)

@@ -318,7 +318,40 @@ def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
     return out
 
 
-def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
+def gemm_prepare_weights(items, n_rows, scratch):
+    """items: [(w [M,K] float32, form 0 forward | 1 dgrad, has_pro, planes uint8 buffer)]: split all these weight matrices
+    into the planes their products over ``n_rows`` rows want, in two launches (ddmp_gemm_prepare_weights).  The GEMM calls
+    then take ``wplanes=planes``.  ``scratch``: float32 [>= 8 len(items)]."""
+    n = len(items)
+    Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _, _ in items])
+    ld = (ctypes.c_int64 * n)(*[w.stride(0) for w, _, _, _ in items])
+    M = (ctypes.c_int * n)(*[w.shape[0] for w, _, _, _ in items])
+    K = (ctypes.c_int * n)(*[w.shape[1] for w, _, _, _ in items])
+    fm = (ctypes.c_int * n)(*[int(f) for _, f, _, _ in items])
+    hp = (ctypes.c_int * n)(*[int(bool(h)) for _, _, h, _ in items])
+    pl = (ctypes.c_void_p * n)(*[p.data_ptr() for _, _, _, p in items])
+    pb = (ctypes.c_size_t * n)(*[p.numel() for _, _, _, p in items])
+    assert scratch.dtype == torch.float32 and scratch.numel() >= 8 * n
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    check(_lib.lib().ddmp_gemm_prepare_weights(n, cast(Wp), cast(ld), cast(M), cast(K), cast(fm), cast(hp), cast(pl), cast(pb),
+                                               int(n_rows), _p(scratch), _stream()), "ddmp_gemm_prepare_weights")
+
+
+def gemm_rows_workspace_bytes(K, M):
+    return int(_lib.lib().ddmp_gemm_rows_workspace_bytes(int(K), int(M)))
+
+
+def _wws(wplanes, nbytes, device):
+    """The weight-plane workspace of a GEMM call: the caller's prepared buffer (announced to the library) or scratch."""
+    if wplanes is not None:
+        if wplanes.numel() < nbytes:
+            raise DdmpError("wplanes: %d bytes, the product needs %d" % (wplanes.numel(), nbytes))
+        _lib.lib().ddmp_gemm_next_prepared()
+        return wplanes
+    return Workspace.get(nbytes, device)
+
+
+def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None):
     """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
     a, lda = _mat(a, "a")
     w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
@@ -331,7 +364,7 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     out, ldy = _mat(out, "out", a)
     ps, psh = (None, None) if pro is None else pro
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    ws = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nt(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
@@ -340,7 +373,7 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
     return out
 
 
-def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None):
+def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None):
     """gemm_nt that also fills ``sums`` (float64 [2M]) with the column sums of out and out^2 (= bn_stats(out)):
     produced in the row-panel kernel's epilogue where that kernel runs, by a separate pass otherwise."""
     if a.dtype == torch.bfloat16:
@@ -381,14 +414,16 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, M)
     ws = Workspace.get(nb + sb, a.device)
+    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
     with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nt_stats_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
-                                      _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream())
+                                      _p(sums), _p(wp), nb if wplanes is None else wp.numel(), ws.data_ptr() + nb,
+                                      ws.numel() - nb, _stream())
     check(st, "ddmp_gemm_nt_stats_f32")
     return out
 
 
-def gemm_nn(a, w, out=None, n_rows=None):
+def gemm_nn(a, w, out=None, n_rows=None, wplanes=None):
     """out[n,K] = a[n,M] @ w[M,K]."""
     a, lda = _mat(a, "a")
     w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
@@ -400,7 +435,7 @@ def gemm_nn(a, w, out=None, n_rows=None):
         out = torch.empty((n, K), dtype=a.dtype, device=a.device)
     out, ldy = _mat(out, "out", a)
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    ws = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nn(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream())
@@ -413,7 +448,7 @@ def gemm_nn_bnred_supported(M, K, n_rows, dtype=torch.float32):
     return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_nn_bnred_supported(int(M), int(K), int(n_rows)))
 
 
-def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None):
+def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplanes=None):
     """out[n,K] = a[n,M] @ w[M,K] AND sums (float64 [2K]) = bn_bwd_reduce(out, yp, bn4): the BatchNorm-backward column
     reductions of `out` as the gradient behind the previous layer's BatchNorm+LeakyReLU (yp: that layer's conv output),
     from the GEMM epilogue -- one read of yp instead of a pass over out and yp."""
@@ -429,10 +464,11 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None):
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
     ws = Workspace.get(nb + sb, a.device)
+    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
     with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nn_bnred_f32(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
-                                      _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb,
-                                      _stream())
+                                      _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(wp), nb if wplanes is None else wp.numel(),
+                                      ws.data_ptr() + nb, ws.numel() - nb, _stream())
     check(st, "ddmp_gemm_nn_bnred_f32")
     return out
 
@@ -489,7 +525,7 @@ def to_bf16(src, dst=None):
     return dst
 
 
-def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
+def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplanes=None):
     """out[n,K] = dY[n,M] @ w[M,K] with dY = BatchNorm+LeakyReLU backward of (dz, yb) computed on the operand load
     (what bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
     if dz.dtype == torch.bfloat16:
@@ -517,7 +553,7 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None):
         out = torch.empty((n, K), dtype=torch.float32, device=dz.device)
     out, ldo = _mat(out, "out")
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
+    ws = _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
     with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
         st = L.ddmp_gemm_nn_bnbwd_f32(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                       _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream())

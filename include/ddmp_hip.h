@@ -289,6 +289,19 @@ int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t 
 /* dgrad of a transform-first layer with the NEXT BatchNorm-backward column reductions from its epilogue (round 3, row-register
  * kernel): out[n,K] = A[n,M] . W[M,K] and sums2[2K] = what ddmp_bn_bwd_reduce_f32(out, Yp, scale, shift, mean, rstd) returns,
  * Yp [n,K] = the previous layer's conv output; stats_ws >= ddmp_gemm_nt_stats_workspace_bytes(n_rows, K) */
+/* Weights prepared once per iteration (round 3).  Every ddmp_gemm_nt* / ddmp_gemm_nn* call splits its weight matrix into
+ * 16-bit planes in its workspace before the product (absolute maximum + split: 2-3 launches per call).
+ * ddmp_gemm_prepare_weights does that for n <= 24 matrices in two launches, into caller-owned buffers planes[i] (>=
+ * ddmp_gemm_rows_workspace_bytes(K[i], M[i]) bytes, 16-byte aligned), in the layout the product over n_rows rows will want:
+ * W[i] is [M[i], K[i]] float32 with leading dimension ldw[i]; form[i] 0 = forward (ddmp_gemm_nt*: Y[n,M] = f(A[n,K]) . W^T,
+ * has_pro[i] = with a prologue), 1 = dgrad (ddmp_gemm_nn*: Y[n,K] = A[n,M] . W).  scratch: 8 n floats.
+ * A GEMM call then passes planes[i] as its `workspace` and is announced by ddmp_gemm_next_prepared() (this host thread, the
+ * NEXT ddmp_gemm_* call): it skips its own split if the buffer was prepared for exactly this matrix, shape and route, and
+ * splits as before otherwise.  The caller re-prepares whenever the weights change. */
+int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, const int* M, const int* K, const int* form,
+                              const int* has_pro /*nullable*/, void* const* planes, const size_t* planes_bytes,
+                              int64_t n_rows, float* scratch, ddmp_stream stream);
+int ddmp_gemm_next_prepared(void);
 int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows);
 int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
                            int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale,

@@ -593,6 +593,43 @@ def test_tail_fused_coefficients_are_bitwise_those_of_the_prepare_kernels(dev, g
     assert torch.equal(dy0, dy1)
 
 
+@pytest.mark.parametrize("n", [3000, 26000])
+def test_prepared_weight_planes_give_the_same_products(dev, n):
+    """ddmp_gemm_prepare_weights: all weight matrices split in two launches into caller-owned plane buffers; the GEMM calls
+    that are handed those buffers skip their own split.  Same values bit for bit on every route (f16x3 / bf16x6 row panels
+    from 20k rows, wave-specialised and plain kernels below), and a buffer prepared for ANOTHER matrix is not trusted."""
+    from dual_dmp_amd import ops
+    torch.manual_seed(n)
+    shapes = [(512, 512), (256, 512), (512, 256), (128, 256), (64, 128), (32, 64), (32, 16), (256, 128)]     # (M = cout, K = cin)
+    ws = [torch.randn(M, K, device=dev) / K ** 0.5 for M, K in shapes]
+    items, bufs = [], {}
+    for i, w in enumerate(ws):
+        for form in (0, 1):
+            buf = torch.empty(ops.gemm_rows_workspace_bytes(w.shape[1], w.shape[0]), dtype=torch.uint8, device=dev)
+            bufs[(i, form)] = buf
+            items.append((w, form, False, buf))
+    ops.gemm_prepare_weights(items, n, torch.empty(8 * len(items), device=dev))
+    for i, w in enumerate(ws):
+        M, K = w.shape
+        a = torch.randn(n, K, device=dev)
+        g = torch.randn(n, M, device=dev)
+        assert torch.equal(ops.gemm_nt(a, w, wplanes=bufs[(i, 0)]), ops.gemm_nt(a, w)), (M, K)
+        assert torch.equal(ops.gemm_nn(g, w, wplanes=bufs[(i, 1)]), ops.gemm_nn(g, w)), (M, K)
+        if M >= 64:
+            s0, s1 = (torch.empty(2 * M, dtype=torch.float64, device=dev) for _ in range(2))
+            y0 = ops.gemm_nt_stats(a, w, s0, wplanes=bufs[(i, 0)])
+            y1 = ops.gemm_nt_stats(a, w, s1)
+            assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    # the weights change (an optimizer step) and nobody re-prepares: announcing the stale buffer with ANOTHER matrix of the
+    # same shape is detected (the library re-splits); re-preparing makes it current again
+    w2 = ws[0] + 1.0
+    a = torch.randn(n, 512, device=dev)
+    assert torch.equal(ops.gemm_nt(a, w2, wplanes=bufs[(0, 0)]), ops.gemm_nt(a, w2))
+    ws[0].add_(0.5)
+    ops.gemm_prepare_weights([(ws[0], 0, False, bufs[(0, 0)])], n, torch.empty(8, device=dev))
+    assert torch.equal(ops.gemm_nt(a, ws[0], wplanes=bufs[(0, 0)]), ops.gemm_nt(a, ws[0]))
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 def test_heads_forward_backward(dev, kind):
     from dual_dmp_amd import ops

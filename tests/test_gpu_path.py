@@ -113,6 +113,7 @@ def _case(dev, which="ico3"):
     v, f = {"ico3": lambda: synth.icosphere(3), "grid": lambda: synth.open_grid(12, 9),
             "cad33": lambda: synth.cube_cad(33),         # 13,068 faces: the fandisk stand-in (README.md:57 of the reference)
             "grid24": lambda: synth.open_grid(24, 17),
+            "torus48k": lambda: synth.torus(220, 110),   # 48,400 faces / 24,200 verts: row-panel routes on both graphs
             "torus144k": lambda: synth.torus(380, 190)}[which]()   # 144,400 faces / 72,200 verts: every bench route is on
     v, f = synth.permute_vertices(v, f, 3)
     gt, noisy, smooth = synth.make_triplet(v, f)
@@ -452,21 +453,25 @@ def test_graph_replay_is_bit_identical_to_eager(dev):
     assert a[5][3] > 0                                     # the gate did open
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_tail_fused_finalisation_is_bit_identical(dev, monkeypatch, dtype):
+@pytest.mark.parametrize("which,dtype", [("grid", torch.float32), ("grid", torch.bfloat16), ("torus48k", torch.float32)])
+def test_launch_fusions_are_bit_identical(dev, monkeypatch, which, dtype):
     """Round 3: BatchNorm coefficients written by the second stage of the reduction that produced their sums
-    (DDMP_TAIL_FUSE, default on) against the stand-alone prepare kernels: the same iteration bit for bit."""
+    (DDMP_TAIL_FUSE) and all weight matrices split once per iteration in two launches (DDMP_PREP_WEIGHTS), both default on,
+    against one prepare kernel per BatchNorm and one split per GEMM call: the same iteration bit for bit -- on a small mesh
+    (plain / wave-specialised GEMM routes) and from 20k rows (row-panel / row-register routes)."""
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
-    gt, noisy, smooth, data = _case(dev, "grid")
+    gt, noisy, smooth, data = _case(dev, which)
     runs = []
     for flag in ("0", "1"):
         monkeypatch.setenv("DDMP_TAIL_FUSE", flag)
+        monkeypatch.setenv("DDMP_PREP_WEIGHTS", flag)
         torch.manual_seed(5)
         posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
         tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=2)
         losses = [tr.step().item() for _ in range(4)]
         assert posnet._engine._tail_fused == (flag == "1")
+        assert (normnet._engine._wplanes is not None) == (flag == "1" and dtype == torch.float32)
         runs.append((losses, tr.pos.clone(), tr.norm.clone(), posnet.arena.data.clone(), normnet.arena.data.clone(),
                      [r.clone() for r in normnet._engine.running]))
     assert runs[0][0] == runs[1][0]
