@@ -53,8 +53,11 @@ template <int VW> __device__ __forceinline__ void ldc(const float* p, float (&v)
 __host__ __device__ inline bool width_ok(int C) { return C >= 8 && C <= 1024 && (C & (C - 1)) == 0; }
 
 int colreduce_blocks(int64_t n_rows, int C, int VW = 4) {
+    // >= 32 row steps per workgroup where the input allows (every workgroup leaves a [2C] float64 record for the second
+    // stage: with 4 steps each a 13k-row input wrote 8 MB of records for 27 MB of data), but never fewer workgroups than CUs
     const int rpi = 256 / (C / VW);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, cdiv(n_rows, (int64_t)rpi * 4)));
+    const int64_t few = cdiv(n_rows, (int64_t)rpi * 4), many = cdiv(n_rows, (int64_t)rpi * 32);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, std::max<int64_t>(many, std::min<int64_t>(kCu, few))));
 }
 
 // F::operator()(row, c0, s0[VW], s1[VW]) accumulates two per-column quantities for columns c0..c0+VW-1

@@ -537,9 +537,19 @@ static int64_t env_rows(const char* name, int64_t dflt) {
 // (DDMP_PANEL_MIN_ROWS / DDMP_TN_PANEL_MIN_ROWS override the thresholds for A/B runs)
 static const int64_t kPanelMinRows = env_rows("DDMP_PANEL_MIN_ROWS", 20000);
 static const int64_t kTnPanelMinRows = env_rows("DDMP_TN_PANEL_MIN_ROWS", 30000);
+static int gemm_f16();
+static bool rr_enabled();
+// The wide f16x3 outputs go to the row-register kernel (gemm_rr.inc: 128-row x 256-column work items, two workgroups per CU,
+// half the MFMA work of bf16x6): worth it from far fewer rows than the 512-thread row panels (DDMP_RR_MIN_ROWS)
+// (13,068-face mesh, replayed graph + two streams: 2.29 ms per iteration with 20000, 2.13 with 10000 -- NormalNet's 13k
+// rows on the kernel --, 2.21 with 3000: PosNet's 6.5k rows = 52 work items are too few for it; 49k faces: 4.04 / 4.00 / 3.92)
+static const int64_t kRRMinRows = env_rows("DDMP_RR_MIN_ROWS", 10000);
+static inline int64_t panel_min_rows(int KD, int MD) {
+    return (MD > 128 && KD >= 64 && KD <= 512 && gemm_f16() && rr_enabled()) ? std::min(kRRMinRows, kPanelMinRows) : kPanelMinRows;
+}
 static inline bool panel_ok(int KD, int MD, const float* Y, int64_t ldy, const void* ws, size_t ws_bytes,
                             int64_t n_rows) {
-    return panel_enabled() && n_rows >= kPanelMinRows && KD % 32 == 0 && KD >= 32 && (KD >= 64 || MD <= 128) &&
+    return panel_enabled() && n_rows >= panel_min_rows(KD, MD) && KD % 32 == 0 && KD >= 32 && (KD >= 64 || MD <= 128) &&
            MD % 4 == 0 && MD >= 16 && MD <= 512 && ws &&
            (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && ws_bytes >= ddmp_gemm_rows_workspace_bytes(KD, MD) &&
            ldy >= MD && Y;
@@ -553,14 +563,12 @@ static bool rr_enabled() {
     }
     return e == 1;
 }
-static const int64_t kRRMinRows = env_rows("DDMP_RR_MIN_ROWS", 20000);
 // (given the f16x3 row-panel route: wide output, f16 mode) does the call take the row-register kernel?
 static inline bool rr_route_ok(int64_t n_rows, int KD, int64_t lda, int64_t lda2) {
     return rr_enabled() && KD >= 64 && KD <= 512 && n_rows >= kRRMinRows &&
            n_rows * lda * 4 < ((int64_t)1 << 32) && n_rows * lda2 * 4 < ((int64_t)1 << 32);      // (32-bit lane offsets)
 }
 // f16 split mode (gemm_f16s.inc): 0 | 13; operand scale slots of the NEXT ddmp_gemm_* call on this host thread
-static int gemm_f16();
 struct ScaleCtx {
     float* a = nullptr;
     float* b = nullptr;
@@ -629,8 +637,8 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
             // row-register kernel (gemm_rr.inc): 128-row tiles x 256-column halves, two workgroups per CU
             const int n_halves = MP / kRRCols;
             const int tiles = (int)ddmp::cdiv(n_rows, kRRRows);
-            int slots = std::min(tiles, 2 * device_cus() / n_halves);
-            slots = std::max(8, slots / 8 * 8);
+            // (a multiple of 8 that covers all tiles in ONE round when they fit: surplus blocks return at once)
+            const int slots = std::max(8, std::min((tiles + 7) / 8 * 8, 2 * device_cus() / n_halves / 8 * 8));
             dim3 rgrid((unsigned)(slots * n_halves)), rblock(256);
             for (int heal = 0; heal <= (prime ? 0 : 1); ++heal) {
                 if (PM == 0 && stats && red_yp)
@@ -837,7 +845,7 @@ extern "C" int ddmp_gemm_prepare_weights(int n, const float* const* W, const int
     if (b.n == 0) return DDMP_OK;
     hipStream_t st = (hipStream_t)stream;
     if (any_f16) hipLaunchKernelGGL(wprep_max_kernel, dim3(8, (unsigned)b.n), dim3(256), 0, st, b, scratch);
-    hipLaunchKernelGGL(wprep_split_kernel, dim3(32, (unsigned)b.n), dim3(256), 0, st, b, (const float*)scratch);
+    hipLaunchKernelGGL(wprep_split_kernel, dim3(128, (unsigned)b.n), dim3(256), 0, st, b, (const float*)scratch);
     LAUNCH_TRY();
     for (int i = 0; i < b.n; ++i) g_w_registry.push_back(b.d[i]);
     return DDMP_OK;
@@ -1066,7 +1074,7 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
 //   layer's BatchNorm+LeakyReLU (Yp = that layer's conv output [n, K]; scale, shift, mean, rstd = its bn4 rows) --
 //   what ddmp_bn_bwd_reduce_f32(out, Yp, ...) returns, without reading out again
 extern "C" int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows) {
-    return gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows && n_rows >= kPanelMinRows &&
+    return gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows &&
                    M % 32 == 0 && M >= 64 && M <= kMaxProK && K > 128 && K <= 512 && K % 4 == 0 ? 1 : 0;
 }
 extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,

@@ -792,8 +792,7 @@ int launch_rr_b16(const bf16_t* A, int64_t lda, const bf16_t* A2, int64_t lda2, 
     LAUNCH_TRY();
     const int n_halves = MPW / kRBCols;
     const int tiles = (int)cdiv(n_rows, kRBRows);
-    int slots = std::min(tiles, 2 * device_cus_b16() / n_halves);
-    slots = std::max(8, slots / 8 * 8);
+    const int slots = std::max(8, std::min((tiles + 7) / 8 * 8, 2 * device_cus_b16() / n_halves / 8 * 8));   // (one round when they fit)
     dim3 grid((unsigned)(slots * n_halves)), block(256);
     double* stats = (double*)stats_ws;
 #define DDMP_RRB(PM_, ST_, NB_)                                                                                        \
