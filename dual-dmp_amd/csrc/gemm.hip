@@ -694,7 +694,7 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         if (mode == 6) DDMP_PANEL(2, 4, 3, 4); else DDMP_PANEL(2, 4, 2, 4);
     } else if (WC == 2) {
         if (mode == 6) DDMP_PANEL(4, 2, 3, 4); else DDMP_PANEL(4, 2, 2, 4);
-    } else if constexpr (PM != 2) {                  // (the fused BatchNorm-backward form exists for wide outputs only)
+    } else {
         if (NJ == 4) {
             if (mode == 6) DDMP_PANEL(8, 1, 3, 4); else DDMP_PANEL(8, 1, 2, 4);
         } else if (NJ == 2) {
@@ -1100,9 +1100,12 @@ extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* 
 
 extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows) {
     if (gemm_mode() == 0 || !panel_enabled() || !tn_panel_enabled() || n_rows < kTnPanelMinRows) return 0;
-    const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin > 128 && cin <= 512;
-    const bool tn = cout >= 256 && cin >= 256 && cout % 4 == 0;
-    return (nn && tn) ? 1 : 0;
+    // wide layers (cin > 128): f16x3 row-register / row-panel dgrad + 256 x 256 wgrad panels; narrow aggregate-first layers
+    // (round 3: 32 -> 64 ... 128 -> 256): the 512-row panel dgrad and the tiled wgrad with the same operand prologue
+    const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin >= 16 && cin <= 512;
+    const bool tn = cout % 4 == 0 && ((cout >= 256 && cin >= 256) || cin <= 128);
+    static const bool narrow = [] { const char* e = getenv("DDMP_BNBWD_NARROW"); return !(e && atoi(e) == 0); }();   // (A/B)
+    return (nn && tn && (cin > 128 || narrow)) ? 1 : 0;
 }
 
 extern "C" int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W,
@@ -1134,12 +1137,33 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     if (!ddmp_gemm_bnbwd_supported(M, K, n_rows)) return DDMP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     TnPlan p = tn_plan(n_rows, M, K);
-    if (p.T != 4) return DDMP_EINVAL;
     const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;
     if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
     float* part = (float*)workspace;
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
+    if (p.T != 4) {                                              // narrow layers: 64 x 64 | 128 x 128 tiles, bf16 split terms
+        const int mode_ = gemm_mode();
+        if (mode_ != 6 && mode_ != 3) return DDMP_EINVAL;
+        dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(256);
+#define DDMP_LAUNCH_TNG(T_, NT_, PRO_)                                                                                 \
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<T_, NT_, PRO_, (T_ == 1 ? 32 : 16), true>), grid, block, 0, st, dZ, lddz, Z, ldz,  \
+                       part, (int64_t)K, sstride, (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k,       \
+                       p.n_splits, pro_scale, pro_shift, slope, Yb, ldyb, a, b, c1, c0)
+        if (p.T == 2) {
+            if (mode_ == 6) { if (pro_scale) DDMP_LAUNCH_TNG(2, 3, true); else DDMP_LAUNCH_TNG(2, 3, false); }
+            else { if (pro_scale) DDMP_LAUNCH_TNG(2, 2, true); else DDMP_LAUNCH_TNG(2, 2, false); }
+        } else {
+            if (mode_ == 6) { if (pro_scale) DDMP_LAUNCH_TNG(1, 3, true); else DDMP_LAUNCH_TNG(1, 3, false); }
+            else { if (pro_scale) DDMP_LAUNCH_TNG(1, 2, true); else DDMP_LAUNCH_TNG(1, 2, false); }
+        }
+#undef DDMP_LAUNCH_TNG
+        LAUNCH_TRY();
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)cdiv((int64_t)M * K, 256)), dim3(256), 0, st, part, sstride,
+                           p.n_splits, dW, lddw, M, K);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     dim3 pgrid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), pblock(512);
     float* gslot = nullptr;
     float* zslot = nullptr;

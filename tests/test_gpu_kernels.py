@@ -178,7 +178,8 @@ def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
         assert relerr(dw, g.double().t() @ f_ref(a.double(), sc.double(), sh.double())) < tol
 
 
-@pytest.mark.parametrize("n,cin,cout", [(65537, 256, 512), (66000, 512, 512), (70001, 256, 256)])
+@pytest.mark.parametrize("n,cin,cout", [(65537, 256, 512), (66000, 512, 512), (70001, 256, 256),
+                                        (65999, 128, 256), (70003, 64, 128), (66001, 32, 64)])     # + narrow aggregate-first layers
 def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     """dgrad / wgrad with the BatchNorm+LeakyReLU backward folded into the operand load == bn_bwd_apply followed by
     the plain GEMMs (same arithmetic per element, so only the GEMM rounding differs) and == the float64 formula."""
