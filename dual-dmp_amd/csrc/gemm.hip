@@ -1108,6 +1108,14 @@ extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows) {
     return (nn && tn && (cin > 128 || narrow)) ? 1 : 0;
 }
 
+// (the wgrad alone: layer 0 has no dgrad)
+extern "C" int ddmp_gemm_tn_bnbwd_supported(int cout, int cin, int64_t n_rows) {
+    if (gemm_mode() == 0 || !tn_panel_enabled() || n_rows < kTnPanelMinRows) return 0;
+    const int mode_ = gemm_mode();
+    const bool panel = cout >= 256 && cin >= 256;
+    return (cout % 4 == 0 && cin % 4 == 0 && (panel || mode_ == 6 || mode_ == 3)) ? 1 : 0;
+}
+
 extern "C" int ddmp_gemm_nn_bnbwd_f32(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W,
                                       int64_t ldw, float* out, int64_t ld_out, int64_t n_rows, int M, int K,
                                       const float* a, const float* b, const float* c1, const float* c0, float slope,
@@ -1134,7 +1142,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     ARG_TRY(dZ && Yb && Z && dW && a && b && c1 && c0 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lddz >= M && ldyb >= M && ldz >= K && lddw >= K);
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
-    if (!ddmp_gemm_bnbwd_supported(M, K, n_rows)) return DDMP_EINVAL;
+    if (!ddmp_gemm_tn_bnbwd_supported(M, K, n_rows)) return DDMP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     TnPlan p = tn_plan(n_rows, M, K);
     const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;

@@ -208,6 +208,10 @@ class GcnEngine:
             except TypeError:                                    # (a stand-in of ops without the dtype argument)
                 return False
         self.fuse_bnbwd = [bool(_bnbwd_ok(l)) for l in range(12)]
+        # layer 0 (no dgrad): its dY feeds the wgrad only
+        tn_ok = getattr(ops, "gemm_tn_bnbwd_supported", None)
+        self.fuse_bnbwd0 = bool(tn_ok and self.agg_first[0] and tn_ok(L.cout[0], L.cin_p[0], self.n_rows, dtype)
+                                and os.environ.get("DDMP_BNBWD_L0", "1") != "0")
         # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
         # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
         # bf16 features: rebuilding dY on the gather reads two rows per CSR entry; measured (scripts/microbench.py spmm
@@ -537,6 +541,10 @@ class GcnEngine:
                 have_sums = dgrad_to_dz(dH, W, dZ, l)
                 wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
                 release(kh)
+                continue
+            if l == 0 and self.fuse_bnbwd0:
+                wgrad(0, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[0], bn4, c10, out=dW, n_rows=n), kz)
+                release(kz)
                 continue
             ky, dY = take(co)
             ops.bn_bwd_apply(dZ, Y, bn4, c10, dY, None, n_rows=n)

@@ -504,6 +504,11 @@ def gemm_bnbwd_supported(cout, cin, n_rows, dtype=torch.float32):
     return bool(_lib.lib().ddmp_gemm_bnbwd_supported(int(cout), int(cin), int(n_rows)))
 
 
+def gemm_tn_bnbwd_supported(cout, cin, n_rows, dtype=torch.float32):
+    """Does gemm_tn_bnbwd exist for cin -> cout over n_rows rows (float32 features; the wgrad alone)?"""
+    return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_tn_bnbwd_supported(int(cout), int(cin), int(n_rows)))
+
+
 def rows_gather(src, idx, out=None, n_rows=None):
     """out[r] = src[idx[r]] (halo packing on the library's kernel; float32 / bfloat16 rows of 16-byte multiples)."""
     src, lds = _mat(src, "src")

@@ -302,6 +302,7 @@ int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, 
                               const int* has_pro /*nullable*/, void* const* planes, const size_t* planes_bytes,
                               int64_t n_rows, float* scratch, ddmp_stream stream);
 int ddmp_gemm_next_prepared(void);
+int ddmp_gemm_tn_bnbwd_supported(int cout, int cin, int64_t n_rows);   /* the fused wgrad alone (a first layer has no dgrad) */
 int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows);
 int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
                            int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale,

@@ -210,6 +210,24 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
 
 
+@pytest.mark.parametrize("cin", [16, 8])
+def test_first_layer_wgrad_with_bn_backward_on_the_load(dev, cin):
+    """Layer 0 has no dgrad: its dY (BatchNorm backward of (dZ, Y), 32 columns) feeds the wgrad only and is rebuilt there."""
+    from dual_dmp_amd import ops
+    n, cout = 70001, 32
+    if not ops.gemm_tn_bnbwd_supported(cout, cin, n):
+        pytest.skip("fused wgrad not available in this GEMM mode")
+    torch.manual_seed(cin)
+    dz, yb, p = torch.randn(n, cout), torch.randn(n, cout) * 2 + 0.5, torch.randn(n, cin)
+    bn4 = torch.stack([torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(cout), torch.rand(cout) + 0.5])
+    c10 = torch.stack([torch.randn(cout) * 0.1, torch.randn(cout) * 0.1])
+    a, b, k1, k0 = bn4[0].double(), bn4[1].double(), c10[0].double(), c10[1].double()
+    z = yb.double() * a + b
+    dy_ref = a * dz.double() * torch.where(z > 0, 1.0, 0.01) + k1 * yb.double() + k0
+    dw = ops.gemm_tn_bnbwd(dz.to(dev), yb.to(dev), p.to(dev), bn4.to(dev), c10.to(dev))
+    assert relerr(dw, dy_ref.t() @ p.double()) < 3e-6
+
+
 def _rr_shapes(seed, count):
     """Random shapes inside the row-register kernel's domain: >= 20k rows (ragged last tiles, fewer tiles than workgroup slots
     and many more), contraction 64..512 in steps of 32, 129..512 output columns in steps of 4 (padded 256 / 512 panels)."""
