@@ -411,23 +411,27 @@ class GcnEngine:
     def backward_steps(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor):
         """Backward pass as a generator (see forward_steps).
 
-        ``async_wgrad`` (opt-in, DDMP_ASYNC_WGRAD=1): every weight gradient (a compute-bound GEMM nothing in this pass
-        waits for) is issued on a second stream, after the dgrad GEMM and beside the HBM-bound kernels that follow
-        (SpMM, BatchNorm passes).  In isolation a 512x512 wgrad and SpMM + reduction take 4.1 ms together against
-        3.7 + 1.6 ms one after the other (scripts/overlap_probe.py); inside the pass the gain is 0.4-0.8 ms per
-        iteration at 1M faces, because the wgrad panels leave the SpMM one wave slot per SIMD.  Work buffers read by a
-        wgrad in flight carry its completion event and are only handed out again after the main stream has waited on
-        it (six buffers in rotation: the wait is long over)."""
+        ``async_wgrad`` (DDMP_ASYNC_WGRAD=1): every weight gradient (a GEMM nothing in this pass waits for) is issued on a
+        further stream, after the dgrad GEMM and beside the kernels that follow (SpMM, BatchNorm passes, the next dgrad).
+        ONE wgrad is in flight at a time: the main stream waits for it right before it forks the next one (or hands out a
+        work buffer it reads), so that every event the main stream waits on is the TAIL of the side stream -- the first
+        form of this (several in flight, buffers guarded by mid-stream events) made hipStreamEndCapture crash."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
         side = self._side_stream() if self.async_wgrad else None
-        free = list(range(len(self._flat)))                     # FIFO: a buffer guarded by a wgrad is reused last
-        guard = {}
+        free = list(range(len(self._flat)))                     # FIFO: a buffer read by the wgrad in flight is reused last
+        pending = [None]                                        # (completion event, work buffers it reads) of that wgrad
+
+        def join():
+            """ONE wgrad in flight: its completion event is always the tail of the side stream (a captured graph whose
+            main stream waited on events in the MIDDLE of the side stream made hipStreamEndCapture crash)."""
+            if pending[0] is not None:
+                torch.cuda.current_stream().wait_event(pending[0][0])
+                pending[0] = None
 
         def take(c):
             k = free.pop(0)
-            ev = guard.pop(k, None)
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+            if pending[0] is not None and k in pending[0][1]:
+                join()
             return k, self._work(k, c)
 
         def release(k):
@@ -439,6 +443,7 @@ class GcnEngine:
                 self._scales(l, 1, 0)
                 fn()
                 return
+            join()
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             side.wait_event(ev)
@@ -447,8 +452,7 @@ class GcnEngine:
                 fn()
                 done = torch.cuda.Event()
                 done.record(side)
-            for k in bufs:
-                guard[k] = done
+            pending[0] = (done, set(bufs))
 
         kz, dZ = take(32)
         if self.perm is not None:
@@ -578,8 +582,7 @@ class GcnEngine:
                     have_sums = dgrad_to_dz(dH, W, dZ, l)
                 wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
                 release(kh)
-        if side is not None:                                     # the gradients are complete when this pass returns
-            torch.cuda.current_stream().wait_stream(side)
+        join()                                                   # the gradients are complete when this pass returns
         if self._f16:
             ops.gemm_scales_roll(self.scale_slots)
             self._prime = False

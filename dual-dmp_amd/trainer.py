@@ -68,7 +68,10 @@ class FusedTrainer:
         # beside them), and hipStreamEndCapture crashes on the resulting graph topology (events waited on that are
         # not the tail of their stream).
         import os
-        self.peng.async_wgrad = self.neng.async_wgrad = (os.environ.get("DDMP_ASYNC_WGRAD") == "1" and not use_graph)
+        # (round 3, one wgrad in flight so that only tail events are waited on: a single-stream capture works and gains
+        # nothing at 13k faces -- 3.13 vs 3.16 ms --, the two-stream capture with a wgrad stream per net still dumps core)
+        self.peng.async_wgrad = self.neng.async_wgrad = (os.environ.get("DDMP_ASYNC_WGRAD") == "1"
+                                                         and not (use_graph and overlap))
         self._graphs = {}       # gate -> torch.cuda.CUDAGraph
         self._warm = False
         self._t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
