@@ -139,3 +139,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "ddmp_oracle" not in txt and "oracle/" not in txt.replace("oracle/README", ""), f
+
+
+def test_row_register_gemm_isa_audit():
+    """The row-register GEMMs count the in-order VMEM counter by hand; that is sound only while their main loops hold no
+    VMEM instruction the counts do not know about (no register-destination load, no scratch reload) and exactly the counted
+    copies and waits per k-step.  scripts/check_rr_asm.py compiles csrc/gemm.hip for gfx950 (device only, no GPU needed)
+    and audits every instantiation -- it is what found the spilled main loop of the reduction epilogue in round 3."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_rr_asm.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "kernels audited: 6, problems: 0" in r.stdout
