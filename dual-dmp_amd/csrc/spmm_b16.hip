@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     __shared__ __attribute__((aligned(16))) uint2 s_ent[kMaxE];  // LEAN: (offset, weight) slots; else: s_col | s_w
     int* s_col = reinterpret_cast<int*>(s_ent);
     float* s_w = reinterpret_cast<float*>(s_ent) + kMaxE;
+    // RED: the previous layer's BatchNorm coefficients, per channel (scale, shift, rstd, -mean * rstd).  In LDS and read per
+    // row: as four per-lane vectors they cost 32 registers (76 in all: 6 waves per SIMD instead of 8) -- the reason this
+    // fused form measured slower than SpMM + reduction pass (round 2: 939 vs 457 + 390 us at C = 512)
+    constexpr int kRedC = 1024;
+    __shared__ __attribute__((aligned(16))) float s_red[RED ? 4 * kRedC : 4];
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -96,6 +101,15 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int e0 = s_rowptr[0];
     const int ne = s_rowptr[nr] - e0;
     const bool staged = ne <= kMaxE;
+    if (RED) {
+        for (int i = tid; i < C; i += 256) {
+            const float rs = red.rstd[i];
+            s_red[i] = red.scale[i];
+            s_red[kRedC + i] = red.shift[i];
+            s_red[2 * kRedC + i] = rs;
+            s_red[3 * kRedC + i] = -red.mean[i] * rs;
+        }
+    }
     if (LEAN) {
         const unsigned ld16 = (unsigned)(ldx >> 3);              // row pitch in 16-byte units
         for (int i = tid; i < nr * stride; i += 256) {
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     for (int c0 = 0; c0 < C; c0 += CS) {
         const int off = c0 + sl * VW;
         float pa[VW], pb[VW], k1[VW], k0[VW];
-        float ra[VW], rb[VW], rmu[VW], rrs[VW], q0[VW], q1[VW];
+        float q0[VW], q1[VW];
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
             pa[j] = 1.f; pb[j] = 0.f; k1[j] = 0.f; k0[j] = 0.f;
@@ -137,12 +151,6 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         if (BWD) {
             ldcf<VW>(bwd.c1 + off, k1);
             ldcf<VW>(bwd.c0 + off, k0);
-        }
-        if (RED) {
-            ldcf<VW>(red.scale + off, ra);
-            ldcf<VW>(red.shift + off, rb);
-            ldcf<VW>(red.mean + off, rmu);
-            ldcf<VW>(red.rstd + off, rrs);
         }
         const bf16_t* xc = X + off;
         const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
@@ -222,11 +230,25 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 float y[VW];
                 PC::unpack(ob, o);
                 PC::unpack(PC::ld(red.Yp + (int64_t)row * red.ldyp + off), y);
+                // four channels at a time, coefficients straight from LDS (opaque offsets: read per row, not hoisted)
 #pragma unroll
-                for (int j = 0; j < VW; ++j) {
-                    const float g = o[j] * lrelu_grad(fmaf(y[j], ra[j], rb[j]), slope);
-                    q0[j] += g;
-                    q1[j] = fmaf(g, (y[j] - rmu[j]) * rrs[j], q1[j]);
+                for (int h = 0; h < VW / 4; ++h) {
+                    int roff = off + 4 * h;
+                    asm volatile("" : "+v"(roff));
+                    const float4 ra = *reinterpret_cast<const float4*>(s_red + roff);
+                    const float4 rb = *reinterpret_cast<const float4*>(s_red + kRedC + roff);
+                    const float4 rrs = *reinterpret_cast<const float4*>(s_red + 2 * kRedC + roff);
+                    const float4 rm = *reinterpret_cast<const float4*>(s_red + 3 * kRedC + roff);
+                    const float a4[4] = {ra.x, ra.y, ra.z, ra.w}, b4[4] = {rb.x, rb.y, rb.z, rb.w};
+                    const float s4[4] = {rrs.x, rrs.y, rrs.z, rrs.w}, m4[4] = {rm.x, rm.y, rm.z, rm.w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * h + jj;
+                        const float g = o[j] * lrelu_grad(fmaf(y[j], a4[jj], b4[jj]), slope);
+                        q0[j] += g;
+                        q1[j] = fmaf(g, fmaf(y[j], s4[jj], m4[jj]), q1[j]);      // yhat = (y - mean) rstd
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
