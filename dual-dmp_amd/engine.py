@@ -492,13 +492,13 @@ class GcnEngine:
         # version lost 0.9 ms: the 32 per-column coefficients of the epilogue were hoisted out of the tile loop as invariants and
         # SPILLED the main loop -- scratch reloads inside the counted-vmcnt pipeline; they now live in LDS and
         # scripts/check_rr_asm.py audits that form too.)  DDMP_GEMM_BNRED=0 for A/B.
-        fuse_dgrad_red = (getattr(ops, "gemm_nn_bnred_supported", None) is not None and isinstance(self.comm, NoComm)
+        fuse_dgrad_red = (getattr(ops, "gemm_nn_bnred_supported", None) is not None
                           and os.environ.get("DDMP_GEMM_BNRED", "1") != "0")
 
         def dgrad_to_dz(dH, W, dZ, l):
             """dZ of layer l-1 = dH . W (transform-first layer l > 0); with that layer's BatchNorm-backward column reductions
-            from the GEMM epilogue where the kernel exists (one device: across devices the sums are all-reduced anyway, but
-            the halo rows of dZ are not this rank's to count -- the epilogue sums owned rows only, which is what n selects)."""
+            from the GEMM epilogue where the kernel exists (across devices too: the epilogue sums this rank's owned rows,
+            which is what n selects, and the sums are all-reduced as after the separate pass)."""
             if fuse_dgrad_red and ops.gemm_nn_bnred_supported(L.cout[l], L.cin_p[l], n, self.dtype):
                 arm(l - 1)
                 ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n, **self._wp(l, 1))
