@@ -329,11 +329,14 @@ class GcnEngine:
             self._wplanes = {(l, form): torch.empty(need(L.cin_p[l], L.cout[l]), dtype=torch.uint8, device=self.device)
                              for l in range(12) for form in (0, 1) if not (form == 1 and l == 0)}
             self._wscratch = torch.empty(8 * len(self._wplanes), dtype=torch.float32, device=self.device)
-        items = []
-        for (l, form), buf in self._wplanes.items():
-            W = L.view(params, "conv%d.lin.weight" % (l + 1), true_shape=False)
-            items.append((W, form, form == 0 and not self.agg_first[l] and l > 0, buf))
-        ops.gemm_prepare_weights(items, self.n_rows, self._wscratch)
+            self._wplan = (None, None)
+        if self._wplan[0] != params.data_ptr():                  # (argument arrays built once per parameter arena)
+            items = []
+            for (l, form), buf in self._wplanes.items():
+                W = L.view(params, "conv%d.lin.weight" % (l + 1), true_shape=False)
+                items.append((W, form, form == 0 and not self.agg_first[l] and l > 0, buf))
+            self._wplan = (params.data_ptr(), ops.WeightPlan(items, self.n_rows, self._wscratch))
+        self._wplan[1].run()
 
     def _wp(self, l, form):
         """Keyword for the GEMM call of layer l (form 0 forward, 1 dgrad): its prepared planes, if any."""

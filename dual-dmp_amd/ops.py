@@ -318,23 +318,36 @@ def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
     return out
 
 
+class WeightPlan:
+    """The argument arrays of one ddmp_gemm_prepare_weights call, built once (the weight matrices are views of a parameter
+    arena whose address does not change between iterations); ``run()`` re-splits the current weights."""
+
+    def __init__(self, items, n_rows, scratch):
+        n = len(items)
+        assert scratch.dtype == torch.float32 and scratch.numel() >= 8 * n
+        self._keep = (items, scratch)
+        self.n, self.n_rows, self.scratch = n, int(n_rows), scratch
+        arrs = ((ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _, _ in items]),
+                (ctypes.c_int64 * n)(*[w.stride(0) for w, _, _, _ in items]),
+                (ctypes.c_int * n)(*[w.shape[0] for w, _, _, _ in items]),
+                (ctypes.c_int * n)(*[w.shape[1] for w, _, _, _ in items]),
+                (ctypes.c_int * n)(*[int(f) for _, f, _, _ in items]),
+                (ctypes.c_int * n)(*[int(bool(h)) for _, _, h, _ in items]),
+                (ctypes.c_void_p * n)(*[p.data_ptr() for _, _, _, p in items]),
+                (ctypes.c_size_t * n)(*[p.numel() for _, _, _, p in items]))
+        self._arrs = arrs
+        self._args = [ctypes.cast(a, ctypes.c_void_p) for a in arrs]
+
+    def run(self):
+        check(_lib.lib().ddmp_gemm_prepare_weights(self.n, *self._args, self.n_rows, _p(self.scratch), _stream()),
+              "ddmp_gemm_prepare_weights")
+
+
 def gemm_prepare_weights(items, n_rows, scratch):
     """items: [(w [M,K] float32, form 0 forward | 1 dgrad, has_pro, planes uint8 buffer)]: split all these weight matrices
     into the planes their products over ``n_rows`` rows want, in two launches (ddmp_gemm_prepare_weights).  The GEMM calls
     then take ``wplanes=planes``.  ``scratch``: float32 [>= 8 len(items)]."""
-    n = len(items)
-    Wp = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _, _, _ in items])
-    ld = (ctypes.c_int64 * n)(*[w.stride(0) for w, _, _, _ in items])
-    M = (ctypes.c_int * n)(*[w.shape[0] for w, _, _, _ in items])
-    K = (ctypes.c_int * n)(*[w.shape[1] for w, _, _, _ in items])
-    fm = (ctypes.c_int * n)(*[int(f) for _, f, _, _ in items])
-    hp = (ctypes.c_int * n)(*[int(bool(h)) for _, _, h, _ in items])
-    pl = (ctypes.c_void_p * n)(*[p.data_ptr() for _, _, _, p in items])
-    pb = (ctypes.c_size_t * n)(*[p.numel() for _, _, _, p in items])
-    assert scratch.dtype == torch.float32 and scratch.numel() >= 8 * n
-    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    check(_lib.lib().ddmp_gemm_prepare_weights(n, cast(Wp), cast(ld), cast(M), cast(K), cast(fm), cast(hp), cast(pl), cast(pb),
-                                               int(n_rows), _p(scratch), _stream()), "ddmp_gemm_prepare_weights")
+    WeightPlan(items, n_rows, scratch).run()
 
 
 def gemm_rows_workspace_bytes(K, M):
