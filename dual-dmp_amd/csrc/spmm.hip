@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 #include "fpartials.inc"
 #include "spmm_lean.inc"
 
-template <bool PRO, bool RED, bool BWD>
+template <bool PRO, int RED, bool BWD>
 int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
                 const float* bias, const float* ps, const float* psh, float slope, hipStream_t st, BnRed red = BnRed(),
                 BnBwdGather bwd = BnBwdGather()) {
@@ -677,6 +677,37 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
     }
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, red_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+// SpMM whose output is a conv output Y (transform-first layers, forward): also returns its BatchNorm statistics
+// (= ddmp_bn_stats_f32(Y)), from the lean kernel's epilogue around the per-column reference `ref` (spmm_lean.inc, RED = 2).
+extern "C" int ddmp_spmm_stats_supported(int C) { return (C % 32 == 0 && C >= 32 && C <= 1024) ? 1 : 0; }
+
+extern "C" int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                                   const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+                                   const float* ref, double* sums2, void* ws, size_t ws_bytes, ddmp_stream stream) {
+    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ARG_TRY(g && X && Y && sums2 && ws && C > 0 && ldx >= C && ldy >= C && X != Y);
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    if (ws_bytes < ddmp_spmm_bnred_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const LeanPlan lp = lean_plan(g, ldx, ldy, C, 2);
+    const bool fused = ref && ddmp_spmm_stats_supported(C) && lp.kind && ldx % 4 == 0 && ldy % 4 == 0 && al16(X) && al16(Y) &&
+                       al16(ref) && al16(ws) && al16(bias) && al16(pro_scale) && al16(pro_shift);
+    if (!fused) {
+        int rc = ddmp_spmm_f32(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, stream);
+        if (rc != DDMP_OK) return rc;
+        return ddmp_bn_stats_f32(Y, ldy, g->n_rows, C, sums2, ws, ws_bytes, stream);
+    }
+    BnRed red{nullptr, 0, nullptr, nullptr, ref, nullptr, (float*)ws};
+    const int rc = pro_scale ? launch_lean<true, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red)
+                             : launch_lean<false, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
+    if (rc != DDMP_OK) return rc;
+    const size_t pbytes = ((size_t)lp.n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
+    fpartials_reduce((const float*)ws, lp.n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -231,7 +231,12 @@ class GcnEngine:
         self.Y = [buf(L.cout[l]) for l in range(12)]                   # conv outputs (pre-BN), saved
         self.P = [buf(L.cin_p[l]) if self.agg_first[l] else None for l in range(12)]
         self._flat = [torch.empty(nc * cmax, dtype=dtype, device=dev) for _ in range(6)]   # work buffers (rotation)
-        self.bn4 = [torch.empty((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
+        # (zeros: row 2 = the last batch mean is the reference of the gather's statistics epilogue in the NEXT iteration)
+        self.bn4 = [torch.zeros((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
+        # transform-first layers, float32: BatchNorm statistics from the gather's epilogue (ddmp_spmm_stats_f32)
+        st_ok = getattr(ops, "spmm_stats_supported", None)
+        self.fuse_spmm_stats = [bool(st_ok) and not self.agg_first[l] and st_ok(L.cout[l], dtype)
+                                and os.environ.get("DDMP_SPMM_STATS", "1") != "0" for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
         # weights split into their 16-bit planes once per iteration, all layers in two launches (float32 features)
@@ -382,8 +387,11 @@ class GcnEngine:
                 self._scales(l, 0)
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0))
                 yield comm.start_halo(H, n)
-                ops.spmm(g, H, out=Y[:n], bias=b)
-                ops.bn_stats(Y, sums=self.sums, n_rows=n)
+                if self.fuse_spmm_stats[l]:
+                    ops.spmm_stats(g, H, Y[:n], self.bn4[l][2], self.sums, bias=b)
+                else:
+                    ops.spmm(g, H, out=Y[:n], bias=b)
+                    ops.bn_stats(Y, sums=self.sums, n_rows=n)
             # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
             # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
             halo_started = l < 11 and self.agg_first[l + 1]

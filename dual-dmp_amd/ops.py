@@ -281,6 +281,29 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
     return out
 
 
+def spmm_stats_supported(C, dtype=torch.float32):
+    """Does spmm_stats take its fused form for C channels (float32 features)?"""
+    return dtype == torch.float32 and bool(_lib.lib().ddmp_spmm_stats_supported(int(C)))
+
+
+def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE):
+    """out = spmm(g, x) (+bias, prologue) and sums (float64 [2C]) = bn_stats(out) from the same kernel: the statistics are
+    summed around ``ref`` (float32 [C], close to the column means -- the previous iteration's batch means; zeros are valid)
+    in float32 over 16 rows at a time, in float64 from there on (ddmp_spmm_stats_f32)."""
+    x, ldx = _mat(_chk(x, torch.float32, "x"), "x")
+    out, ldy = _mat(_chk(out, torch.float32, "out"), "out")
+    C = x.shape[1]
+    ps, psh = (None, None) if pro is None else pro
+    L = _lib.lib()
+    ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, F32), x.device)
+    alg = 4.0 * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
+        st = L.ddmp_spmm_stats_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope,
+                                   _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_spmm_stats_f32")
+    return out
+
+
 def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
     """out = spmm(g, x) (a gradient dZ) and sums2 = bn_bwd_reduce(out, yp, bn4) from the same kernel."""
     x, ldx = _mat(x, "x")

@@ -260,6 +260,18 @@ int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float*
                         const float* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
                         const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace,
                         size_t workspace_bytes, ddmp_stream stream);
+/* GCNConv.propagate of a transform-first layer (forward) that also returns the BatchNorm statistics of its output
+ * (float64 [2C]: column sums of Y and of Y^2 = ddmp_bn_stats_f32(Y)) from the gather kernel's epilogue (round 3).  `ref`
+ * [C]: a per-column reference near the column means (the caller's previous batch means; zeros are valid): the kernel
+ * sums (y - ref) and (y - ref)^2 in float32 over 16 rows at a time and in float64 from there on, and the shift is undone
+ * exactly -- around ref those partial sums are well conditioned whatever mean / std is (float32-class statistics, as
+ * nn.BatchNorm1d computes them).  Workspace: ddmp_spmm_bnred_workspace_bytes(n_rows, C).  Where the fused kernel does not
+ * apply (C % 32, misaligned, ref NULL) it runs ddmp_spmm_f32 + ddmp_bn_stats_f32. */
+int ddmp_spmm_stats_supported(int C);
+int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
+                        const float* bias /*nullable*/, const float* pro_scale /*nullable*/,
+                        const float* pro_shift /*nullable*/, float slope, const float* ref /*[C], nullable*/,
+                        double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
 /* backward of GCNConv.propagate of a transform-first layer, with the backward of the BatchNorm1d+LeakyReLU behind it
  * (util/networks.py:51-62 under autograd) rebuilt on the gather: out = A_hat . dY,
  * dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0 per column (what ddmp_bn_bwd_apply_f32 would have written and this

@@ -101,6 +101,42 @@ def test_spmm_with_bn_backward_reduce(dev, graphs, C):
         assert relerr(sums, ref_s) < 1e-5, (gname, relerr(sums, ref_s))
 
 
+@pytest.mark.parametrize("C", [32, 256, 64, 16])
+def test_spmm_with_forward_statistics(dev, graphs, C):
+    """SpMM + the BatchNorm statistics of its output from one kernel (transform-first layers, forward): the output is the
+    plain kernel's bit for bit; the statistics are summed around a per-column reference in float32 over 16 rows, float64
+    from there on -- with a reference near the mean (what the engine passes: the previous iteration's batch mean) the
+    variance keeps float32-class accuracy even when |mean| >> std; C = 16 takes the unfused route (exact)."""
+    from dual_dmp_amd import ops
+    for gname in graphs:
+        ei, n = graphs[gname]
+        torch.manual_seed(C + n)
+        g = ops.graph_for(ei.to(dev), n)
+        bias = (torch.randn(C) * 50).to(dev)                       # column means far from 0: |mean| / std up to ~100
+        x = torch.randn(n, C, device=dev)
+        ref_y = ops.spmm(g, x, bias=bias)
+        s_ref = ops.bn_stats(ref_y)
+        mean = (s_ref[:C] / n).float()
+        var_ref = (s_ref[C:] / n - (s_ref[:C] / n) ** 2)
+        for ref, tol_var in ((mean * 1.01, 2e-5), (torch.zeros(C, device=dev), None)):
+            out = torch.empty_like(ref_y)
+            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            ops.spmm_stats(g, x, out, ref.contiguous(), sums, bias=bias)
+            assert torch.equal(out, ref_y)
+            assert relerr(sums, s_ref) < 2e-6, (gname, relerr(sums, s_ref))
+            var = sums[C:] / n - (sums[:C] / n) ** 2
+            if tol_var is not None:
+                assert float(((var - var_ref).abs() / var_ref).max()) < tol_var, (gname, float(((var - var_ref).abs() / var_ref).max()))
+        # with the tail-fused coefficients on top
+        bn4, run = torch.zeros(4, C, device=dev), torch.stack([torch.zeros(C), torch.ones(C)]).to(dev)
+        gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        ops.bn_next_prepare(n, gamma, beta, bn4, running=(run[0], run[1]))
+        ops.spmm_stats(g, x, out, (mean * 1.01).contiguous(), sums, bias=bias)
+        want = torch.zeros(4, C, device=dev)
+        ops.bn_prepare(sums, n, gamma, beta, want)
+        assert torch.equal(bn4, want)
+
+
 @pytest.mark.parametrize("C", [32, 256, 64])
 def test_spmm_with_bn_backward_on_the_gather(dev, graphs, C):
     """A_hat . dY with dY = BatchNorm+LeakyReLU backward of (dZ, Y) rebuilt on the gather == bn_bwd_apply followed by
