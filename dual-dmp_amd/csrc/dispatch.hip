@@ -123,6 +123,14 @@ extern "C" int ddmp_spmm_bnred(const ddmp_graph* g, const void* X, int64_t ldx, 
                ? ddmp_spmm_bnred_bf16(g, (cb)X, ldx, (uint16_t*)Y, ldy, C, (cb)Yp, ldyp, scale, shift, mean, rstd, slope, sums2, ws, wsb, st)
                : ddmp_spmm_bnred_f32(g, (cf)X, ldx, (float*)Y, ldy, C, (cf)Yp, ldyp, scale, shift, mean, rstd, slope, sums2, ws, wsb, st);
 }
+extern "C" int ddmp_spmm_stats(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+                               const float* bias, const float* ps, const float* psh, float slope, const float* ref,
+                               double* sums2, void* ws, size_t wsb, ddmp_stream st) {
+    ddmp::FinalizeScope fin_scope(sums2, st);
+    ARG_TRY(dt_ok(dtype));
+    return dtype == DDMP_BF16 ? ddmp_spmm_stats_bf16(g, (cb)X, ldx, (uint16_t*)Y, ldy, C, bias, ps, psh, slope, ref, sums2, ws, wsb, st)
+                              : ddmp_spmm_stats_f32(g, (cf)X, ldx, (float*)Y, ldy, C, bias, ps, psh, slope, ref, sums2, ws, wsb, st);
+}
 extern "C" int ddmp_spmm_bnbwd(const ddmp_graph* g, const void* dZ, int64_t lddz, const void* Yb, int64_t ldyb, void* out,
                                int64_t ld_out, int C, int dtype, const float* a, const float* b, const float* c1,
                                const float* c0, float slope, ddmp_stream st) {

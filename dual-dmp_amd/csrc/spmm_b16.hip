@@ -68,7 +68,9 @@ template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f
 // at staging time -- an entry is (row offset in 16-byte units, weight), rows own fixed slots of `stride` entries padded to
 // whole quads with weight-0 copies of their last entry -- so the address of a gathered piece is one v_lshl_add_u64 on the
 // lane's slab base and the inner loop reads four entries with two ds_read_b128, without clamping or branches.
-template <int VW, int LANES, int U, bool PRO, bool RED, bool BWD, bool LEAN>
+// RED: 0 | 1 BatchNorm-backward reductions of the output | 2 BatchNorm statistics of the (rounded) output around red.mean
+// (see spmm_lean.inc)
+template <int VW, int LANES, int U, bool PRO, int RED, bool BWD, bool LEAN>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     // row: as four per-lane vectors they cost 32 registers (76 in all: 6 waves per SIMD instead of 8) -- the reason this
     // fused form measured slower than SpMM + reduction pass (round 2: 939 vs 457 + 390 us at C = 512)
     constexpr int kRedC = 1024;
-    __shared__ __attribute__((aligned(16))) float s_red[RED ? 4 * kRedC : 4];
+    __shared__ __attribute__((aligned(16))) float s_red[RED == 1 ? 4 * kRedC : RED == 2 ? kRedC : 4];
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int e0 = s_rowptr[0];
     const int ne = s_rowptr[nr] - e0;
     const bool staged = ne <= kMaxE;
-    if (RED) {
+    if (RED == 1) {
         for (int i = tid; i < C; i += 256) {
             const float rs = red.rstd[i];
             s_red[i] = red.scale[i];
@@ -110,6 +112,8 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
             s_red[3 * kRedC + i] = -red.mean[i] * rs;
         }
     }
+    if (RED == 2)
+        for (int i = tid; i < C; i += 256) s_red[i] = red.mean[i];
     if (LEAN) {
         const unsigned ld16 = (unsigned)(ldx >> 3);              // row pitch in 16-byte units
         for (int i = tid; i < nr * stride; i += 256) {
@@ -226,7 +230,23 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
             for (int j = 0; j < VW; ++j) o[j] = fmaf(acc[j], di, bs[j]);
             const typename PC::raw ob = PC::pack(o);
             PC::st(Y + (int64_t)row * ldy + off, ob);
-            if (RED) {                                           // on the values as stored (rounded)
+            if (RED == 2) {                                      // statistics of the values as stored (rounded), around ref
+                PC::unpack(ob, o);
+#pragma unroll
+                for (int h = 0; h < VW / 4; ++h) {
+                    int roff = off + 4 * h;
+                    asm volatile("" : "+v"(roff));
+                    const float4 rf = *reinterpret_cast<const float4*>(s_red + roff);
+                    const float r4[4] = {rf.x, rf.y, rf.z, rf.w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float d = o[4 * h + jj] - r4[jj];
+                        q0[4 * h + jj] += d;
+                        q1[4 * h + jj] = fmaf(d, d, q1[4 * h + jj]);
+                    }
+                }
+            }
+            if (RED == 1) {                                      // on the values as stored (rounded)
                 float y[VW];
                 PC::unpack(ob, o);
                 PC::unpack(PC::ld(red.Yp + (int64_t)row * red.ldyp + off), y);
@@ -274,7 +294,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
 
 #include "fpartials.inc"
 
-template <int VW, int LANES, bool PRO, bool RED, bool BWD>
+template <int VW, int LANES, bool PRO, int RED, bool BWD>
 int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red, BnBwdGatherB bwd) {
     const int n = (int)g->n_rows;
@@ -299,7 +319,7 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
     return DDMP_OK;
 }
 
-template <bool PRO, bool RED, bool BWD>
+template <bool PRO, int RED, bool BWD>
 int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                  const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red = BnRedB(),
                  BnBwdGatherB bwd = BnBwdGatherB()) {
@@ -312,7 +332,7 @@ int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, i
         const char* e = getenv("DDMP_SPMM_B16_VW");
         vw_fused = (e && atoi(e) == 4) ? 4 : 8;
     }
-    constexpr bool kFused = PRO || RED || BWD;
+    constexpr bool kFused = PRO || RED != 0 || BWD;
     if (kFused && vw_fused == 4) {
         if (C % 64 == 0) return launch_b16<4, 16, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
         if (C % 32 == 0) return launch_b16<4, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
@@ -372,6 +392,32 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                                    const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+                                    const float* ref, double* sums2, void* ws, size_t ws_bytes, ddmp_stream stream) {
+    // = ddmp_spmm_bf16 + ddmp_bn_stats_bf16 of the stored output, the statistics from the gather's epilogue around `ref`
+    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ARG_TRY(g && X && Y && sums2 && ws && X != Y && shape_ok(X, ldx, Y, ldy, C));
+    ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
+    ARG_TRY(coef_ok(bias) && coef_ok(pro_scale) && coef_ok(pro_shift) && coef_ok(ref) && b16_aligned(ws));
+    if (ws_bytes < ddmp_spmm_bnred_bf16_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ref || C % 16 != 0 || C > 1024) {
+        int rc = ddmp_spmm_bf16(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, stream);
+        if (rc != DDMP_OK) return rc;
+        return ddmp_bn_stats_bf16(Y, ldy, g->n_rows, C, sums2, ws, ws_bytes, stream);
+    }
+    const int n_chunks = (int)cdiv(g->n_rows, kRB);
+    BnRedB red{nullptr, 0, nullptr, nullptr, ref, nullptr, (float*)ws};
+    const int rc = pro_scale ? dispatch_b16<true, 2, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red)
+                             : dispatch_b16<false, 2, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
+    if (rc != DDMP_OK) return rc;
+    const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
+    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -235,7 +235,10 @@ class GcnEngine:
         self.bn4 = [torch.zeros((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         # transform-first layers, float32: BatchNorm statistics from the gather's epilogue (ddmp_spmm_stats_f32)
         st_ok = getattr(ops, "spmm_stats_supported", None)
-        self.fuse_spmm_stats = [bool(st_ok) and not self.agg_first[l] and st_ok(L.cout[l], dtype)
+        # (bf16 features: the same epilogue exists and measures a tie with the separate pass -- 26.87 / 26.93 vs 26.98 / 26.77 ms
+        # per step --: off unless DDMP_SPMM_STATS_BF16=1)
+        st_dt = dtype == torch.float32 or os.environ.get("DDMP_SPMM_STATS_BF16") == "1"
+        self.fuse_spmm_stats = [bool(st_ok) and st_dt and not self.agg_first[l] and st_ok(L.cout[l], dtype)
                                 and os.environ.get("DDMP_SPMM_STATS", "1") != "0" for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)

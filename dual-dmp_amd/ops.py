@@ -282,25 +282,28 @@ def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
 
 
 def spmm_stats_supported(C, dtype=torch.float32):
-    """Does spmm_stats take its fused form for C channels (float32 features)?"""
+    """Does spmm_stats take its fused form for C channels?"""
+    if dtype == torch.bfloat16:
+        return C % 16 == 0 and C <= 1024
     return dtype == torch.float32 and bool(_lib.lib().ddmp_spmm_stats_supported(int(C)))
 
 
 def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE):
     """out = spmm(g, x) (+bias, prologue) and sums (float64 [2C]) = bn_stats(out) from the same kernel: the statistics are
     summed around ``ref`` (float32 [C], close to the column means -- the previous iteration's batch means; zeros are valid)
-    in float32 over 16 rows at a time, in float64 from there on (ddmp_spmm_stats_f32)."""
-    x, ldx = _mat(_chk(x, torch.float32, "x"), "x")
-    out, ldy = _mat(_chk(out, torch.float32, "out"), "out")
+    in float32 over 16 rows at a time, in float64 from there on (ddmp_spmm_stats)."""
+    x, ldx = _mat(x, "x")
+    out, ldy = _mat(out, "out", x)
     C = x.shape[1]
     ps, psh = (None, None) if pro is None else pro
     L = _lib.lib()
-    ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, F32), x.device)
-    alg = 4.0 * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
+    ws = Workspace.get(max(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), L.ddmp_colreduce_workspace_bytes(g.n_rows, C)), x.device)
+    es = x.element_size()
+    alg = float(es) * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
-        st = L.ddmp_spmm_stats_f32(g.handle, _p(x), ldx, _p(out), ldy, C, _p(bias), _p(ps), _p(psh), slope,
-                                   _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream())
-    check(st, "ddmp_spmm_stats_f32")
+        st = L.ddmp_spmm_stats(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
+                               _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream())
+    check(st, "ddmp_spmm_stats")
     return out
 
 

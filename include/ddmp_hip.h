@@ -272,6 +272,14 @@ int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float*
                         const float* bias /*nullable*/, const float* pro_scale /*nullable*/,
                         const float* pro_shift /*nullable*/, float slope, const float* ref /*[C], nullable*/,
                         double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
+                         const float* bias /*nullable*/, const float* pro_scale /*nullable*/,
+                         const float* pro_shift /*nullable*/, float slope, const float* ref /*[C], nullable*/,
+                         double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
+/* dtype-tagged form; workspace >= max(ddmp_spmm_bnred_ws_bytes, ddmp_colreduce_workspace_bytes) */
+int ddmp_spmm_stats(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+                    const float* bias, const float* pro_scale, const float* pro_shift, float slope, const float* ref,
+                    double* sums2, void* workspace, size_t workspace_bytes, ddmp_stream stream);
 /* backward of GCNConv.propagate of a transform-first layer, with the backward of the BatchNorm1d+LeakyReLU behind it
  * (util/networks.py:51-62 under autograd) rebuilt on the gather: out = A_hat . dY,
  * dY = a * dZ * lrelu'(a * Yb + b) + c1 * Yb + c0 per column (what ddmp_bn_bwd_apply_f32 would have written and this

@@ -101,8 +101,9 @@ def test_spmm_with_bn_backward_reduce(dev, graphs, C):
         assert relerr(sums, ref_s) < 1e-5, (gname, relerr(sums, ref_s))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C", [32, 256, 64, 16])
-def test_spmm_with_forward_statistics(dev, graphs, C):
+def test_spmm_with_forward_statistics(dev, graphs, C, dtype):
     """SpMM + the BatchNorm statistics of its output from one kernel (transform-first layers, forward): the output is the
     plain kernel's bit for bit; the statistics are summed around a per-column reference in float32 over 16 rows, float64
     from there on -- with a reference near the mean (what the engine passes: the previous iteration's batch mean) the
@@ -113,7 +114,7 @@ def test_spmm_with_forward_statistics(dev, graphs, C):
         torch.manual_seed(C + n)
         g = ops.graph_for(ei.to(dev), n)
         bias = (torch.randn(C) * 50).to(dev)                       # column means far from 0: |mean| / std up to ~100
-        x = torch.randn(n, C, device=dev)
+        x = torch.randn(n, C, device=dev).to(dtype)
         ref_y = ops.spmm(g, x, bias=bias)
         s_ref = ops.bn_stats(ref_y)
         mean = (s_ref[:C] / n).float()
