@@ -690,7 +690,21 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
     hipLaunchKernelGGL((gemm_panel_kernel<WR_, WC_, NT_, PM, NJ_>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy, \
                        n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, (float*)nullptr,            \
                        (const float*)nullptr, 0, 0)
-    if (WC == 4) {
+    if (WC == 1 && PM == 0 && stats && red_yp && (NJ == 4 || NJ == 2)) {
+        // narrow transform-first dgrads (outputs of 128 | 64 columns) with the next BatchNorm-backward reductions
+#define DDMP_PANEL_RS(NT_, NJ_)                                                                                     \
+    hipLaunchKernelGGL((gemm_panel_kernel<8, 1, NT_, 0, NJ_, true>), grid, block, 0, st, A, lda, A2, lda2, Bp, Y, ldy, \
+                       n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, n_row_tiles, stats, (float*)nullptr,            \
+                       (const float*)nullptr, 0, 0, red_yp, red_ldyp, red_bn4[0], red_bn4[1], red_bn4[2], red_bn4[3])
+        if constexpr (PM == 0) {
+            if (NJ == 4) {
+                if (mode == 6) DDMP_PANEL_RS(3, 4); else DDMP_PANEL_RS(2, 4);
+            } else {
+                if (mode == 6) DDMP_PANEL_RS(3, 2); else DDMP_PANEL_RS(2, 2);
+            }
+        }
+#undef DDMP_PANEL_RS
+    } else if (WC == 4) {
         if (mode == 6) DDMP_PANEL(2, 4, 3, 4); else DDMP_PANEL(2, 4, 2, 4);
     } else if (WC == 2) {
         if (mode == 6) DDMP_PANEL(4, 2, 3, 4); else DDMP_PANEL(4, 2, 2, 4);
@@ -1074,8 +1088,13 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
 //   layer's BatchNorm+LeakyReLU (Yp = that layer's conv output [n, K]; scale, shift, mean, rstd = its bn4 rows) --
 //   what ddmp_bn_bwd_reduce_f32(out, Yp, ...) returns, without reading out again
 extern "C" int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows) {
-    return gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows &&
-                   M % 32 == 0 && M >= 64 && M <= kMaxProK && K > 128 && K <= 512 && K % 4 == 0 ? 1 : 0;
+    if (gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows && M % 32 == 0 && M >= 64 &&
+        M <= kMaxProK && K > 128 && K <= 512 && K % 4 == 0)
+        return 1;                                                // wide outputs: row-register kernel, STATS = 2
+    static const bool narrow = [] { const char* e = getenv("DDMP_GEMM_BNRED_NARROW"); return !(e && atoi(e) == 0); }();   // (A/B)
+    // narrow outputs (128 | 64 columns): the 512-row panel kernel's RS epilogue (bf16 split terms)
+    return (narrow && (gemm_mode() == 6 || gemm_mode() == 3) && panel_enabled() && n_rows >= kPanelMinRows && M % 32 == 0 &&
+            M >= 32 && M <= kMaxProK && (K == 128 || K == 64)) ? 2 : 0;
 }
 extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
                                       int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale,
@@ -1087,8 +1106,8 @@ extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* 
     ARG_TRY(A && W && out && Yp && scale && shift && mean && rstd && sums2 && n_rows > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ld_out >= K && ldyp >= K);
     ARG_TRY(aligned16(A) && aligned16(W));
-    if (!ddmp_gemm_nn_bnred_supported(M, K, n_rows) || !rr_route_ok(n_rows, M, lda, 0) ||
-        !panel_ok(M, K, out, ld_out, workspace, workspace_bytes, n_rows))
+    const int form = ddmp_gemm_nn_bnred_supported(M, K, n_rows);
+    if (!form || (form == 1 && !rr_route_ok(n_rows, M, lda, 0)) || !panel_ok(M, K, out, ld_out, workspace, workspace_bytes, n_rows))
         return DDMP_EINVAL;
     if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, K)) return DDMP_EWORKSPACE;
     const float* bn4[4] = {scale, shift, mean, rstd};

@@ -309,7 +309,8 @@ def test_row_register_gemm_random_shapes(dev, f16x3, n, K, M):
             assert relerr(dx, dy @ w.double()) < 3e-6
 
 
-@pytest.mark.parametrize("n,M,K", [(66001, 256, 512), (40000, 128, 256), (33000, 512, 512), (20300, 64, 256)])
+@pytest.mark.parametrize("n,M,K", [(66001, 256, 512), (40000, 128, 256), (33000, 512, 512), (20300, 64, 256),
+                                   (70001, 64, 128), (66003, 32, 64), (25000, 256, 128)])      # + narrow outputs (row-panel kernel)
 def test_gemm_nn_with_bn_backward_reductions(dev, n, M, K):
     """dgrad of a transform-first layer with the next BatchNorm-backward column reductions from its epilogue (row-register
     kernel) == gemm_nn followed by bn_bwd_reduce of its output, and == the float64 formulas."""
