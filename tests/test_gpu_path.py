@@ -337,6 +337,12 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect
             assert sum(eng.fuse_bnbwd) >= 4 and sum(eng.fuse_gather_bwd) >= 3, (eng.fuse_bnbwd, eng.fuse_gather_bwd)
             assert ops.gemm_bnbwd_supported(512, 256, eng.n_rows) and ops.get_gemm_mode() == 13
             assert ops.gemm_nn_bnred_supported(256, 512, eng.n_rows) and eng._tail_fused
+            # round 3: every aggregate-first layer rebuilds dY on its GEMMs' operand loads (layer 0: on the wgrad alone), every
+            # transform-first dgrad returns the next reductions from its epilogue, the weights are split once per iteration
+            assert all(eng.fuse_bnbwd[l] for l in range(1, 12) if eng.agg_first[l]) and eng.fuse_bnbwd0
+            assert all(ops.gemm_nn_bnred_supported(eng.layout.cout[l], eng.layout.cin_p[l], eng.n_rows)
+                       for l in range(1, 12) if not eng.agg_first[l])
+            assert eng._prep_weights
     for it in range(1, iters + 1):
         if it in check_at:
             for which, (net, ref, opt) in enumerate(((posnet, rp, op), (normnet, rn, on))):
