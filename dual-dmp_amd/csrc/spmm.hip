@@ -500,7 +500,17 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
                 BnBwdGather bwd = BnBwdGather()) {
     const int n = (int)g->n_rows;
     const int cpx = (int)cdiv(lp.n_chunks, kXcd);
-    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
+    // small graphs: split the slabs of a chunk over several workgroups (the staged CSR slice is cheap to repeat) until ~2048
+    // workgroups exist -- a workgroup per 64 rows alone leaves a 13k-row graph with 205 long-running workgroups on 256 CUs
+    int groups = 1;
+    const int n_slabs = C / 32;
+    static const bool split_on = [] { const char* e = getenv("DDMP_SPMM_SLAB_GROUPS"); return !(e && atoi(e) == 0); }();   // (A/B)
+    if (split_on && lp.n_chunks < 1024 && n_slabs > 1) {
+        const int want = std::min(n_slabs, std::max(1, 2048 / std::max(lp.n_chunks, 1)));
+        const int per = (n_slabs + want - 1) / want;
+        groups = (n_slabs + per - 1) / per;
+    }
+    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
                        Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, lp.stride, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
