@@ -259,6 +259,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         if (s + 1 < n_slabs) slab(s + 1, std::integral_constant<int, 1>());
         if constexpr (kNB > 2) {
             if (s + 2 < n_slabs) slab(s + 2, std::integral_constant<int, 2>());
+        }
+        if constexpr (kNB > 3) {
             if (s + 3 < n_slabs) slab(s + 3, std::integral_constant<int, 3>());
         }
     }
@@ -396,7 +398,7 @@ int patch_nb() {                                                  // DDMP_SPMM_P
     static int nb = 0;
     if (!nb) {
         const char* e = getenv("DDMP_SPMM_PATCH_NB");
-        nb = (e && atoi(e) == 4) ? 4 : 2;
+        nb = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 3) ? 3 : 2;
     }
     return nb;
 }
@@ -431,6 +433,7 @@ template <typename T, int KD, bool PRO, bool RED>
 int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                   const float* psh, float slope, hipStream_t st, RedArgs red) {
     if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
     return launch_patch2nb<T, KD, PRO, RED, 2>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
