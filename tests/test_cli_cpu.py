@@ -20,6 +20,13 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None) == -1
     assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, 0, None) == -1
     assert lib.ddmp_gemm_tn_workspace_bytes(1000000, 512, 512) > 0
+    # round 3 entry points: argument checks need no device either
+    assert lib.ddmp_bn_next_prepare(0.0, 32, None, None, 1e-5, 0.1, None, None, None, None, None, None) == -1
+    assert lib.ddmp_bn_next_bwd_prepare(10.0, 0, None, None, None, None, None, None, None) == -1
+    assert lib.ddmp_bn_next_cancel() == 0
+    assert lib.ddmp_gemm_prepare_weights(25, None, None, None, None, None, None, None, None, 1000, None, None) == -1   # > 24 matrices
+    assert lib.ddmp_gemm_next_prepared() == 0
+    assert lib.ddmp_spmm_stats_supported(256) == 1 and lib.ddmp_spmm_stats_supported(40) == 0
 
 
 def test_host_csr_matches_gcn_norm(oracle):
