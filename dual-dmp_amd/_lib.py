@@ -90,7 +90,7 @@ def lib():
             raise DdmpError("libddmp_hip.so does not export %s (declared in include/ddmp_hip.h)" % name)
         fn.restype = _RET[ret]
         fn.argtypes = [t for t, _ in sig]
-    if handle.ddmp_abi_version() != 1:
+    if handle.ddmp_abi_version() != 2:
         raise DdmpError("libddmp_hip.so ABI version mismatch")
     _lib = handle
     return _lib
@@ -103,4 +103,5 @@ def status_string(st: int) -> str:
 
 def check(st: int, what: str = ""):
     if st != 0:
+        lib().ddmp_next_cancel()         # nothing armed for "the next call" survives an error (include/ddmp_hip.h, ABI 2)
         raise DdmpError("%s failed: status %d (%s)" % (what or "ddmp call", st, status_string(st)))

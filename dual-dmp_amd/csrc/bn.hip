@@ -280,7 +280,7 @@ extern "C" size_t ddmp_colreduce_workspace_bytes(int64_t n_rows, int C) {
 
 extern "C" int ddmp_bn_stats_f32(const float* Y, int64_t ldy, int64_t n_rows, int C, double* sums,
                                  void* ws, size_t ws_bytes, ddmp_stream stream) {
-    FinalizeScope fin_scope(sums, stream);
+    FinalizeScope fin_scope(sums, stream, C);
     ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && ldy % 4 == 0);
     StatsF<float> f{Y, ldy};
     return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
@@ -318,7 +318,7 @@ extern "C" int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float
                                       int64_t n_rows, int C, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, float slope, double* sums2,
                                       void* ws, size_t ws_bytes, ddmp_stream stream) {
-    FinalizeScope fin_scope(sums2, stream);
+    FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && ldy >= C && lddz >= C && ldy % 4 == 0 && lddz % 4 == 0);
     BwdReduceF<float> f{dZ, Y, scale, shift, mean, rstd, lddz, ldy, slope};
@@ -389,7 +389,7 @@ extern "C" int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_str
 // per lane, float32 arithmetic, float64 sums; C a power of two in [16, 1024]; workspace = ddmp_colreduce_workspace_bytes
 extern "C" int ddmp_bn_stats_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, int C, double* sums, void* ws,
                                   size_t ws_bytes, ddmp_stream stream) {
-    FinalizeScope fin_scope(sums, stream);
+    FinalizeScope fin_scope(sums, stream, C);
     ARG_TRY(Y && sums && n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && ldy % 8 == 0 && b16_aligned(Y));
     StatsF<bf16_t> f{Y, ldy};
     return run_colreduce(f, n_rows, C, 2 * C, sums, ws, ws_bytes, (hipStream_t)stream);
@@ -399,7 +399,7 @@ extern "C" int ddmp_bn_bwd_reduce_bf16(const uint16_t* dZ, int64_t lddz, const u
                                        int C, const float* scale, const float* shift, const float* mean,
                                        const float* rstd, float slope, double* sums2, void* ws, size_t ws_bytes,
                                        ddmp_stream stream) {
-    FinalizeScope fin_scope(sums2, stream);
+    FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(dZ && Y && scale && shift && mean && rstd && sums2);
     ARG_TRY(n_rows > 0 && n_rows < INT32_MAX && width_ok(C) && C >= 16 && ldy >= C && lddz >= C && ldy % 8 == 0 && lddz % 8 == 0);
     ARG_TRY(b16_aligned(dZ) && b16_aligned(Y));

@@ -46,11 +46,13 @@ FinalizeArgs finalize_take(int C) {
     g_fin_active = FinalizeArgs();
     return f;
 }
-FinalizeScope::FinalizeScope(const double* sums_, ddmp_stream stream) : sums(sums_), st((hipStream_t)stream), owns(false) {
+FinalizeScope::FinalizeScope(const double* sums_, ddmp_stream stream, int width)
+    : sums(sums_), st((hipStream_t)stream), owns(false) {
     if (g_fin_pending.kind != 0) {
-        g_fin_active = g_fin_pending;
-        g_fin_pending = FinalizeArgs();
-        owns = true;
+        const bool fits = g_fin_pending.C == width && sums_ != nullptr;
+        if (fits) g_fin_active = g_fin_pending;
+        g_fin_pending = FinalizeArgs();                          // consumed or dropped: never left for a later call
+        owns = fits;
     }
 }
 FinalizeScope::~FinalizeScope() {
@@ -92,6 +94,14 @@ extern "C" int ddmp_bn_next_cancel(void) {
     ddmp::finalize_pending() = ddmp::FinalizeArgs();
     return DDMP_OK;
 }
+// bit 0: BatchNorm coefficients armed (ddmp_bn_next_*), bit 1: GEMM scale slots named (ddmp_gemm_next_scales), bit 2: prepared
+// weight planes announced (ddmp_gemm_next_prepared)
+extern "C" int ddmp_next_pending(void) { return (ddmp::finalize_pending().kind != 0 ? 1 : 0) | ddmp::gemm_next_pending(); }
+extern "C" int ddmp_next_cancel(void) {
+    ddmp::finalize_pending() = ddmp::FinalizeArgs();
+    ddmp::gemm_next_cancel();
+    return DDMP_OK;
+}
 
 extern "C" int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream) {
     ARG_TRY(in && out && n > 0);
@@ -126,7 +136,7 @@ extern "C" int ddmp_spmm_bnred(const ddmp_graph* g, const void* X, int64_t ldx, 
 extern "C" int ddmp_spmm_stats(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
                                const float* bias, const float* ps, const float* psh, float slope, const float* ref,
                                double* sums2, void* ws, size_t wsb, ddmp_stream st) {
-    ddmp::FinalizeScope fin_scope(sums2, st);
+    ddmp::FinalizeScope fin_scope(sums2, st, C);
     ARG_TRY(dt_ok(dtype));
     return dtype == DDMP_BF16 ? ddmp_spmm_stats_bf16(g, (cb)X, ldx, (uint16_t*)Y, ldy, C, bias, ps, psh, slope, ref, sums2, ws, wsb, st)
                               : ddmp_spmm_stats_f32(g, (cf)X, ldx, (float*)Y, ldy, C, bias, ps, psh, slope, ref, sums2, ws, wsb, st);
@@ -166,14 +176,14 @@ extern "C" int ddmp_gemm_tn(const void* G, int64_t ldg, const void* Z, int64_t l
 }
 extern "C" int ddmp_bn_stats(const void* Y, int64_t ldy, int64_t n, int C, int dtype, double* sums, void* ws, size_t wsb,
                              ddmp_stream st) {
-    ddmp::FinalizeScope fin_scope(sums, st);
+    ddmp::FinalizeScope fin_scope(sums, st, C);
     ARG_TRY(dt_ok(dtype));
     return dtype == DDMP_BF16 ? ddmp_bn_stats_bf16((cb)Y, ldy, n, C, sums, ws, wsb, st) : ddmp_bn_stats_f32((cf)Y, ldy, n, C, sums, ws, wsb, st);
 }
 extern "C" int ddmp_bn_bwd_reduce(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t n, int C, int dtype,
                                   const float* scale, const float* shift, const float* mean, const float* rstd, float slope,
                                   double* sums2, void* ws, size_t wsb, ddmp_stream st) {
-    ddmp::FinalizeScope fin_scope(sums2, st);
+    ddmp::FinalizeScope fin_scope(sums2, st, C);
     ARG_TRY(dt_ok(dtype));
     return dtype == DDMP_BF16 ? ddmp_bn_bwd_reduce_bf16((cb)dZ, lddz, (cb)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st)
                               : ddmp_bn_bwd_reduce_f32((cf)dZ, lddz, (cf)Y, ldy, n, C, scale, shift, mean, rstd, slope, sums2, ws, wsb, st);

@@ -61,12 +61,19 @@ FinalizeArgs finalize_take(int C);
 
 // At the top of every extern "C" entry that produces a float64 [2C] column reduction.  Nested entries (a fused form falling
 // back to GEMM + ddmp_bn_stats) share the outermost scope's request.
+// `width` = the columns of THIS call's reduction: a pending request for another width (armed for a call that was never made:
+// an error or an exception in the caller in between) is DROPPED here, never run against sums of another size; so is a
+// request whose call has no sums buffer (argument error).
 struct FinalizeScope {
     const double* sums;
     hipStream_t st;
     bool owns;
-    FinalizeScope(const double* sums_, ddmp_stream stream);
+    FinalizeScope(const double* sums_, ddmp_stream stream, int width);
     ~FinalizeScope();                                            // request still open: stand-alone prepare kernel
 };
+// everything armed on this host thread for "the next call" (ddmp_next_pending / ddmp_next_cancel of the C ABI); the GEMM
+// side's share lives in gemm.hip
+int gemm_next_pending();
+void gemm_next_cancel();
 
 }  // namespace ddmp

@@ -16,6 +16,7 @@
 // fetched from HBM once and re-read from that XCD's L2; W (<= 1 MiB) lives in every L2.
 #include "ddmp_common.h"
 #include "finalize.h"
+#include "gemm_tn_rm.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -575,6 +576,13 @@ struct ScaleCtx {
     int prime = 0;
 };
 static thread_local ScaleCtx g_scale_ctx;
+namespace ddmp {
+int gemm_next_pending() { return ((g_scale_ctx.a || g_scale_ctx.b || g_scale_ctx.prime) ? 2 : 0) | (g_w_next_prepared ? 4 : 0); }
+void gemm_next_cancel() {
+    g_scale_ctx = ScaleCtx();
+    g_w_next_prepared = false;
+}
+}  // namespace ddmp
 static ScaleCtx take_scale_ctx() {                               // (top of every GEMM entry point)
     ScaleCtx c = g_scale_ctx;
     g_scale_ctx = ScaleCtx();
@@ -838,6 +846,13 @@ extern "C" int ddmp_gemm_next_prepared(void) {
     g_w_next_prepared = true;
     return DDMP_OK;
 }
+// the owner of a plane buffer is about to free it (or to stop maintaining it): drop what this thread recorded for it, so that
+// a later allocation at the same address is never taken for prepared planes.  planes == NULL: everything.
+extern "C" int ddmp_gemm_forget_planes(const void* planes) {
+    for (size_t e = 0; e < g_w_registry.size();)
+        if (planes == nullptr || g_w_registry[e].planes == planes) g_w_registry.erase(g_w_registry.begin() + e); else ++e;
+    return DDMP_OK;
+}
 
 extern "C" int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, const int* M, const int* K,
                                          const int* form, const int* has_pro, void* const* planes, const size_t* planes_bytes,
@@ -990,6 +1005,23 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     return DDMP_OK;
 }
 
+// The wide f16x3 wgrad: row-major staging kernel of round 4 (gemm_tn_rm.hip); DDMP_TN_RM=0 keeps the round-3 panel kernel (A/B)
+static bool tn_rm_enabled() {
+    static const bool e = [] { const char* v = getenv("DDMP_TN_RM"); return !(v && atoi(v) == 0); }();
+    return e;
+}
+static void launch_tn_wide(const float* G, int64_t ldg, const float* G2, int64_t ldg2, const float* Z, int64_t ldz, float* part,
+                           int64_t sstride, int64_t n_rows, int M, int K, const TnPlan& p, const float* ps, const float* psh,
+                           const float* ga, const float* gb, const float* gk1, const float* gk0, float slope, float* gslot,
+                           float* zslot, int target, int heal, hipStream_t st) {
+    ddmp::TnRmArgs a;
+    a.G = G; a.ldg = ldg; a.G2 = G2; a.ldg2 = ldg2; a.Z = Z; a.ldz = ldz; a.part = part; a.ld_out = K; a.split_stride = sstride;
+    a.n_rows = (int)n_rows; a.M = M; a.K = K; a.rows_per_split = p.rows_per_split; a.n_tiles_m = p.n_tiles_m;
+    a.n_tiles_k = p.n_tiles_k; a.n_splits = p.n_splits; a.pscale = ps; a.pshift = psh; a.ga = ga; a.gb = gb; a.gk1 = gk1;
+    a.gk0 = gk0; a.slope = slope; a.gslot = gslot; a.zslot = zslot; a.target = target; a.heal = heal;
+    ddmp::launch_tn_rm(a, st);
+}
+
 extern "C" size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K) {
     if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
     TnPlan p = tn_plan(n_rows, M, K);
@@ -1036,8 +1068,12 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
                 if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
                 else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
             }
+            const bool rm = tn_rm_enabled() && ldg * 4 < (int64_t)1 << 31 && ldz * 4 < (int64_t)1 << 31;
             for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {      // second launch: redo on overflow (gemm_f16s.inc)
-                if (pro_scale) {
+                if (rm) {
+                    launch_tn_wide(G, ldg, nullptr, 0, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, nullptr, nullptr,
+                                   nullptr, nullptr, slope, gslot, zslot, target, heal_, st);
+                } else if (pro_scale) {
                     DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, false>));
                 } else {
                     DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, false>));
@@ -1101,7 +1137,7 @@ extern "C" int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* 
                                       const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
                                       void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
                                       ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, K);
     const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(A && W && out && Yp && scale && shift && mean && rstd && sums2 && n_rows > 0 && n_rows < INT32_MAX);
     ARG_TRY(M % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= M && ldw >= K && ld_out >= K && ldyp >= K);
@@ -1212,8 +1248,13 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
             if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
             else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
         }
+        const bool rm = tn_rm_enabled() && lddz * 4 < (int64_t)1 << 31 && ldyb * 4 < (int64_t)1 << 31 && ldz * 4 < (int64_t)1 << 31 &&
+                        aligned16(dZ) && aligned16(Yb) && aligned16(Z);
         for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {          // second launch: redo on overflow (gemm_f16s.inc)
-            if (pro_scale) {
+            if (rm) {
+                launch_tn_wide(dZ, lddz, Yb, ldyb, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, a, b, c1, c0, slope,
+                               gslot, zslot, target, heal_, st);
+            } else if (pro_scale) {
                 DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, true>));
             } else {
                 DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, true>));
@@ -1247,7 +1288,7 @@ extern "C" int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* 
                                       const float* pro_shift, float slope, double* sums2, void* workspace,
                                       size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
                                       ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, M);
     const ScaleCtx ctx = take_scale_ctx();
     ARG_TRY(sums2 && stats_ws);
     if (stats_ws_bytes < ddmp_gemm_nt_stats_workspace_bytes(n_rows, M)) return DDMP_EWORKSPACE;

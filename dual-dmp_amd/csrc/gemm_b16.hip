@@ -901,7 +901,7 @@ extern "C" int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const flo
                                        int64_t n_rows, int K, int M, const float* bias, const float* pro_scale,
                                        const float* pro_shift, float slope, double* sums2, void* workspace,
                                        size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, M);
     ARG_TRY(A && W && Y && sums2 && n_rows > 0 && n_rows < INT32_MAX && K > 0 && M > 0 && ldw >= K);
     ARG_TRY(lda >= K && ldy >= M && lda % 8 == 0 && ldy % 8 == 0 && b16_aligned(A) && b16_aligned(Y));
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));

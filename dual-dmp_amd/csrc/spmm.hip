@@ -644,7 +644,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
                                    const float* Yp, int64_t ldyp, const float* scale, const float* shift,
                                    const float* mean, const float* rstd, float slope, double* sums2, void* ws,
                                    size_t ws_bytes, ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && C > 0 && ldx >= C && ldy >= C && ldyp >= C);
     ARG_TRY(X != Y);
     if (ws_bytes < ddmp_spmm_bnred_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;
@@ -698,7 +698,7 @@ extern "C" int ddmp_spmm_stats_supported(int C) { return (C % 32 == 0 && C >= 32
 extern "C" int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
                                    const float* bias, const float* pro_scale, const float* pro_shift, float slope,
                                    const float* ref, double* sums2, void* ws, size_t ws_bytes, ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(g && X && Y && sums2 && ws && C > 0 && ldx >= C && ldy >= C && X != Y);
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
     if (ws_bytes < ddmp_spmm_bnred_workspace_bytes(g->n_rows, C)) return DDMP_EWORKSPACE;

@@ -377,7 +377,7 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
                                     const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift,
                                     const float* mean, const float* rstd, float slope, double* sums2, void* ws,
                                     size_t ws_bytes, ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(g && X && Y && Yp && scale && shift && mean && rstd && sums2 && ws && X != Y && shape_ok(X, ldx, Y, ldy, C));
     ARG_TRY(ldyp >= C && ldyp % 8 == 0 && b16_aligned(Yp) && b16_aligned(ws));
     ARG_TRY(coef_ok(scale) && coef_ok(shift) && coef_ok(mean) && coef_ok(rstd));
@@ -400,7 +400,7 @@ extern "C" int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int6
                                     const float* bias, const float* pro_scale, const float* pro_shift, float slope,
                                     const float* ref, double* sums2, void* ws, size_t ws_bytes, ddmp_stream stream) {
     // = ddmp_spmm_bf16 + ddmp_bn_stats_bf16 of the stored output, the statistics from the gather's epilogue around `ref`
-    ddmp::FinalizeScope fin_scope(sums2, stream);
+    ddmp::FinalizeScope fin_scope(sums2, stream, C);
     ARG_TRY(g && X && Y && sums2 && ws && X != Y && shape_ok(X, ldx, Y, ldy, C));
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
     ARG_TRY(coef_ok(bias) && coef_ok(pro_scale) && coef_ok(pro_shift) && coef_ok(ref) && b16_aligned(ws));

@@ -318,38 +318,85 @@ class NativeComm:
         torch.cuda.synchronize(self.device)
         self.dist.barrier()
 
-    def self_check(self, plan: "HaloPlan") -> bool:
+    def _check_inputs(self, plan):
+        """Test tensors of the self-check + what torch.distributed delivers for them (reference collectives: run by EVERY rank,
+        unconditionally and in the same order, before anything native can fail)."""
+        dev = self.device
+        ids = torch.from_numpy(np.asarray(plan.local_ids, dtype=np.float64)).to(dev)
+        t = torch.zeros((plan.n_cols, 4), dtype=torch.float32, device=dev)
+        t[: plan.n_rows, 0] = (ids[: plan.n_rows] % 8191.0).float()
+        t[: plan.n_rows, 1] = torch.div(ids[: plan.n_rows], 8191.0, rounding_mode="floor").float()
+        t[: plan.n_rows, 2] = float(self.rank)
+        ref = t.clone()
+        send = ref[: plan.n_rows].index_select(0, torch.from_numpy(plan.send_idx).to(dev)).contiguous()
+        recv = ref[plan.n_rows: plan.n_cols]
+        self.dist.all_to_all_single(recv, send, output_split_sizes=list(plan.recv_counts),
+                                    input_split_sizes=list(plan.send_counts))
+        sums = torch.arange(8, dtype=torch.float64, device=dev) + self.rank
+        sums_ref = sums.clone()
+        self.dist.all_reduce(sums_ref)
+        return ids, t, ref, sums, sums_ref
+
+    @staticmethod
+    def _check_verdict(plan, ids, t, ref, sums, sums_ref):
+        want = ids[plan.n_rows: plan.n_cols]
+        got = t[plan.n_rows: plan.n_cols, 0].double() + 8191.0 * t[plan.n_rows: plan.n_cols, 1].double()
+        return bool(torch.equal(t, ref) and torch.equal(got, want) and torch.equal(sums, sums_ref))
+
+    def self_check(self, plan: "HaloPlan", other: "NativeComm" = None, other_plan: "HaloPlan" = None) -> bool:
         """World size > 1, before the first step: push a tensor of GLOBAL row ids through this communicator's grouped halo
         exchange and a float64 vector through its all-reduce, and compare with what torch.distributed delivers for the
         same plan (all_to_all_single / all_reduce: the path the gloo world-2 tests cover).  Every rank returns the same
         verdict (the flags are all-reduced through torch.distributed): False = do not use this backend.  The native
         send/recv path cannot be run with peers in the build loop (one-GPU boxes; RCCL refuses two ranks on one device),
-        so it proves itself on the job's own plan before it is trusted."""
+        so it proves itself on the job's own plan before it is trusted.
+
+        ``other`` / ``other_plan``: a second communicator that the trainer will drive CONCURRENTLY on a side stream (PosNet
+        beside NormalNet); its exchange is enqueued on a second stream before the first one is waited for, i.e. both
+        communicators are in flight on the device at once, as in the step.
+
+        The torch.distributed reference collectives run outside the guarded region and the verdict all-reduce is reached at
+        the same collective index on every rank whatever the native calls do.  A native exchange that HANGS (mismatched
+        order, a peer that never posts) cannot be recovered in-process: a watchdog ends the process with exit code 17
+        after DDMP_SELFCHECK_TIMEOUT seconds (default 180) and says which switch selects the torch.distributed backend."""
+        import os
+        import sys
+        import threading
         dev = self.device
+        with ops.on_device(dev):
+            a = self._check_inputs(plan)
+            b = other._check_inputs(other_plan) if other is not None else None
+            torch.cuda.synchronize(dev)
+        limit = float(os.environ.get("DDMP_SELFCHECK_TIMEOUT", "180"))
+
+        def _give_up():
+            sys.stderr.write("ddmp: the native RCCL self-check did not complete within %.0f s on rank %d -- exiting (17).  "
+                             "DDMP_DIST_NATIVE=0 selects the torch.distributed backend, DDMP_DIST_STREAMS=0 a single "
+                             "communicator.\n" % (limit, self.rank))
+            sys.stderr.flush()
+            os._exit(17)
+
+        dog = threading.Timer(limit, _give_up)
+        dog.daemon = True
+        dog.start()
         ok = 1.0
         try:
             with ops.on_device(dev):
-                ids = torch.from_numpy(np.asarray(plan.local_ids, dtype=np.float64)).to(dev)
-                t = torch.zeros((plan.n_cols, 4), dtype=torch.float32, device=dev)
-                t[: plan.n_rows, 0] = (ids[: plan.n_rows] % 8191.0).float()
-                t[: plan.n_rows, 1] = torch.div(ids[: plan.n_rows], 8191.0, rounding_mode="floor").float()
-                t[: plan.n_rows, 2] = float(self.rank)
-                ref = t.clone()
-                send = ref[: plan.n_rows].index_select(0, torch.from_numpy(plan.send_idx).to(dev)).contiguous()
-                recv = ref[plan.n_rows: plan.n_cols]
-                self.dist.all_to_all_single(recv, send, output_split_sizes=list(plan.recv_counts),
-                                            input_split_sizes=list(plan.send_counts))
-                sums = torch.arange(8, dtype=torch.float64, device=dev) + self.rank
-                sums_ref = sums.clone()
-                self.dist.all_reduce(sums_ref)
-                self.halo_exchange_native(plan, t, sums)
+                side = torch.cuda.Stream(device=dev) if other is not None else None
+                if other is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        other.halo_exchange_native(other_plan, b[1], b[3])
+                self.halo_exchange_native(plan, a[1], a[3])
                 torch.cuda.synchronize(dev)
-                want = ids[plan.n_rows: plan.n_cols]
-                got = t[plan.n_rows: plan.n_cols, 0].double() + 8191.0 * t[plan.n_rows: plan.n_cols, 1].double()
-                if not (torch.equal(t, ref) and torch.equal(got, want) and torch.equal(sums, sums_ref)):
+                if not self._check_verdict(plan, *a):
+                    ok = 0.0
+                if other is not None and not self._check_verdict(other_plan, *b):
                     ok = 0.0
         except Exception:       # noqa: BLE001
             ok = 0.0
+        finally:
+            dog.cancel()
         flag = torch.tensor([ok], dtype=torch.float32, device=dev)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         return bool(flag.item() > 0.5)
@@ -896,7 +943,10 @@ def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnflo
         if torch.device(device).type == "cuda" and os.environ.get("DDMP_DIST_NATIVE", "1") != "0":
             try:
                 backend = NativeComm(device)
-                if os.environ.get("DDMP_DIST_STREAMS", "1") != "0":
+                # Two communicators driven concurrently on two streams have run at world size 1 only (no multi-GPU box in
+                # the build loop): with peers they are OPT-IN (DDMP_DIST_STREAMS=1) and then have to pass the concurrent
+                # self-check below; the default with peers is one communicator, one stream.
+                if os.environ.get("DDMP_DIST_STREAMS", "1" if world == 1 else "0") != "0":
                     backend_pos = NativeComm(device)
             except Exception as e:      # noqa: BLE001  (every rank takes the same branch: RCCL is there for all or none)
                 import warnings
@@ -910,7 +960,9 @@ def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnflo
     posnet, normnet = nets
     sharded = ShardedData(dataset, n_mesh, rank, world)
     if isinstance(backend, NativeComm) and backend.world_size > 1 and not kw.get("_skip_self_check"):
-        good = backend.self_check(sharded.fplan) and (backend_pos is None or backend_pos.self_check(sharded.vplan))
+        good = backend.self_check(sharded.fplan)
+        if good and backend_pos is not None:                     # each alone, then both in flight at once
+            good = backend_pos.self_check(sharded.vplan) and backend.self_check(sharded.fplan, backend_pos, sharded.vplan)
         if not good:
             import warnings
             warnings.warn("the native RCCL backend failed its self-check against torch.distributed on this job's halo plan: "

@@ -271,6 +271,17 @@ class GcnEngine:
             self.inv[self.perm] = torch.arange(self.n_rows, device=dev)
             self.out_orig = torch.empty_like(self.out)
 
+    def __del__(self):
+        # the library's prepared-planes registry must not outlive the plane buffers (an allocation that reuses their address
+        # would be taken for prepared planes)
+        try:
+            planes = getattr(self, "_wplanes", None)
+            if planes and hasattr(ops, "gemm_forget_planes"):
+                for buf in planes.values():
+                    ops.gemm_forget_planes(buf)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def _work(self, i, c):
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
 
@@ -357,6 +368,8 @@ class GcnEngine:
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
         (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        if hasattr(ops, "next_cancel"):
+            ops.next_cancel()                                     # nothing armed by an aborted earlier pass survives
         self.n_forward = getattr(self, "n_forward", 0) + 1        # (dist: cache key of the all-gathered outputs)
         self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
         self._prepare_weights(params)
@@ -432,6 +445,8 @@ class GcnEngine:
         work buffer it reads), so that every event the main stream waits on is the TAIL of the side stream -- the first
         form of this (several in flight, buffers guarded by mid-stream events) made hipStreamEndCapture crash."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
+        if hasattr(ops, "next_cancel"):
+            ops.next_cancel()
         side = self._side_stream() if self.async_wgrad else None
         free = list(range(len(self._flat)))                     # FIFO: a buffer read by the wgrad in flight is reused last
         pending = [None]                                        # (completion event, work buffers it reads) of that wgrad

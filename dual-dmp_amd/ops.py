@@ -107,6 +107,24 @@ def get_gemm_mode() -> int:
     return int(_lib.lib().ddmp_get_gemm_mode())
 
 
+def next_pending() -> int:
+    """Bit mask of what is armed for "the next call" on this host thread (1 BatchNorm coefficients, 2 GEMM scale slots,
+    4 prepared weight planes)."""
+    return int(_lib.lib().ddmp_next_pending())
+
+
+def next_cancel():
+    """Drop everything armed for "the next call" on this host thread.  The engines call it at the top of every forward /
+    backward pass (an exception between arming and the armed call -- in user code, in a hook -- must not attach coefficients
+    or scale slots to a later, unrelated launch); a failing ddmp call cancels by itself (_lib.check)."""
+    _lib.lib().ddmp_next_cancel()
+
+
+def gemm_forget_planes(planes=None):
+    """The prepared-planes registry forgets ``planes`` (a buffer about to be freed; None: everything)."""
+    _lib.lib().ddmp_gemm_forget_planes(_p(planes))
+
+
 def gemm_next_scales(slot_a, slot_b=None, prime=False):
     """f16 split modes: name the scale slots (float32 [4] device tensors, persistent) of the operands of the NEXT gemm_*
     call -- slot_a: the row operand (a / dz / g), slot_b: z of the tn forms.  Without this the library measures every

@@ -34,7 +34,8 @@ extern "C" {
 #define DDMP_ENOMEM (-3)      /* host allocation failed */
 #define DDMP_EWORKSPACE (-4)  /* caller workspace too small */
 
-#define DDMP_ABI_VERSION 1      /* additions only since round 1: the *_bf16 and dtype-tagged entry points */
+#define DDMP_ABI_VERSION 2      /* 2 (round 4): rules for the "armed for the next call" state + ddmp_next_pending / ddmp_next_cancel /
+                                   ddmp_gemm_forget_planes; additions only otherwise (the *_bf16 and dtype-tagged entry points) */
 
 typedef struct ddmp_graph ddmp_graph;
 typedef void* ddmp_stream;    /* hipStream_t */
@@ -78,7 +79,9 @@ int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, in
                   const float* bias, const float* pro_scale, const float* pro_shift, float slope,
                   ddmp_stream stream);
 
-/* ------------------------------------------------------------------ dense steps (MFMA, exact f32)
+/* ------------------------------------------------------------------ dense steps (MFMA; float32 operands and results, the
+ * arithmetic is ddmp_set_gemm_mode's: by default SPLIT-precision 16-bit MFMA products with f32 accumulation -- f32-class
+ * accuracy, not bit-exact f32; mode 0 = f32-input MFMA, the strict one)
  * Replace GCNConv.lin (X.W^T, no bias) and its autograd (dX = dH.W, dW = dH^T.X).
  *   nt : Y[n,M] = f(A[n,K]) . W[M,K]^T (+ bias[M])       forward / dgrad with a transposed table
  *   nn : Y[n,K] =   A[n,M]  . W[M,K]                     dgrad
@@ -156,6 +159,13 @@ int ddmp_bn_next_prepare(double n_total, int C, const float* gamma, const float*
 int ddmp_bn_next_bwd_prepare(double n_total, int C, const float* scale, const float* mean, const float* rstd,
                              float* dgamma, float* dbeta, float* c1, float* c0);
 int ddmp_bn_next_cancel(void);
+/* Everything "armed for the next call" on this host thread -- ddmp_bn_next_* (bit 0), ddmp_gemm_next_scales (bit 1),
+ * ddmp_gemm_next_prepared (bit 2) -- as a bit mask, and a cancel for all of it.  Rules of the armed state (ABI 2): it is
+ * consumed or DROPPED by the next entry point of its family whether that call succeeds or returns an error; a BatchNorm
+ * request is only attached to a reduction of its own width C and only when the call has a sums buffer; a host mirror that
+ * arms and calls in two steps cancels in its error path (dual-dmp_amd/ops.py: `armed`). */
+int ddmp_next_pending(void);
+int ddmp_next_cancel(void);
 /* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias; dbias_sums NULL: dY only -- behind
  * a BatchNorm those sums are zero in exact arithmetic) */
 int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, float* dY, int64_t lddy,
@@ -322,6 +332,8 @@ int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, 
                               const int* has_pro /*nullable*/, void* const* planes, const size_t* planes_bytes,
                               int64_t n_rows, float* scratch, ddmp_stream stream);
 int ddmp_gemm_next_prepared(void);
+/* the owner of a plane buffer is about to free it: drop what this thread recorded for it (NULL: everything) */
+int ddmp_gemm_forget_planes(const void* planes);
 int ddmp_gemm_tn_bnbwd_supported(int cout, int cin, int64_t n_rows);   /* the fused wgrad alone (a first layer has no dgrad) */
 int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows);
 int ddmp_gemm_nn_bnred_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,

@@ -100,10 +100,49 @@ def test_loss_ltype_conventions(dev, golden_dir):
     from dual_dmp_amd import loss as L
     m = _golden_mesh(golden_dir, "grid4")
     pos = torch.zeros(len(m.vs), 3, device=dev)
-    with pytest.raises(NotImplementedError):
-        L.pos_rec_loss(pos, m.vs, ltype="l1mae")
     with pytest.raises(SystemExit):                      # reference: print("[ERROR]: ltype error"); exit()
         L.pos_rec_loss(pos, m.vs, ltype="bogus")
+    with pytest.raises(SystemExit):
+        L.fn_bnf_loss(pos, torch.zeros(len(m.faces), 3, device=dev), m, ltype="cos")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_non_default_ltypes_match_reference_golden(dev, golden_dir, name):
+    """The ltype variants neither driver uses (util/loss.py:22,43,62-77,119-130,153): values, result dtypes and autograd
+    gradients against vectors captured from the reference (tests/golden/ltype_*.npz, same inputs as loss_*.npz)."""
+    from dual_dmp_amd import loss as L
+    gl = np.load(os.path.join(golden_dir, "loss_%s.npz" % name))
+    gv = np.load(os.path.join(golden_dir, "ltype_%s.npz" % name))
+    m = _golden_mesh(golden_dir, name)
+
+    def leaf(a):
+        return torch.from_numpy(a).to(dev).requires_grad_(True)
+
+    pos, nrm = leaf(gl["pos"]), leaf(gl["norm"])
+    l = L.pos_rec_loss(pos, m.vs, ltype="l1mae")
+    assert l.dtype == torch.float64
+    np.testing.assert_allclose(l.item(), gv["pos_rec_l1mae"], rtol=1e-9)
+    assert relerr(torch.autograd.grad(l, pos)[0], gv["pos_rec_l1mae_dpos"]) < 1e-6
+    l = L.mesh_laplacian_loss(pos, m, ltype="mae")
+    assert l.dtype == torch.float32
+    np.testing.assert_allclose(l.item(), gv["lap_mae"], rtol=1e-5)
+    assert relerr(torch.autograd.grad(l, pos)[0], gv["lap_mae_dpos"]) < 1e-5
+    for lt in ("l2mae", "l2rmse", "l1rmse", "cos"):
+        l = L.norm_rec_loss(nrm, m.fn, ltype=lt)
+        assert l.dtype == torch.float64, lt
+        np.testing.assert_allclose(l.item(), gv["norm_rec_%s" % lt], rtol=1e-9, err_msg=lt)
+        assert relerr(torch.autograd.grad(l, nrm)[0], gv["norm_rec_%s_dnorm" % lt]) < 1e-6, lt
+    for lt in ("mae", "rmse", "l1rmse"):
+        for loop in (1, 5):
+            l, new_fn = L.fn_bnf_loss(pos, nrm, m, ltype=lt, loop=loop)
+            assert l.dtype == torch.float32
+            np.testing.assert_allclose(l.item(), gv["bnf%d_%s" % (loop, lt)], rtol=2e-5, err_msg="%s %d" % (lt, loop))
+            assert relerr(new_fn, gl["bnf%d_newfn" % loop]) < 1e-5
+            assert relerr(torch.autograd.grad(l, nrm)[0], gv["bnf%d_%s_dnorm" % (loop, lt)]) < 1e-4, (lt, loop)
+    l = L.pos_norm_loss(pos, nrm, m, ltype="rmse")
+    np.testing.assert_allclose(l.item(), gv["pos_norm_rmse"], rtol=1e-5)
+    gp, gn = torch.autograd.grad(l, [pos, nrm])
+    assert relerr(gp, gv["pos_norm_rmse_dpos"]) < 1e-5 and relerr(gn, gv["pos_norm_rmse_dnorm"]) < 1e-5
 
 
 # ------------------------------------------------------------------------------------ nets
@@ -457,6 +496,40 @@ def test_graph_replay_is_bit_identical_to_eager(dev):
         for x, y in zip(a[1:], b[1:]):
             assert torch.equal(x, y), key
     assert a[5][3] > 0                                     # the gate did open
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_timed_configuration_is_bit_identical_to_eager_at_144k(dev, dtype):
+    """The configuration bench.py times -- one replayed hipGraph per iteration, PosNet on a second stream -- against the eager
+    single-stream trainer at 144,400 faces / 72,200 vertices, where every large-mesh route is on (row-register / panel GEMMs
+    sharing a CU two workgroups at a time, stale-scale + heal launches, fused BatchNorm epilogues): 4 iterations across the
+    BNF gate flip (eager first iteration, capture, replay, re-capture), bit-identical losses, outputs, parameters, running
+    statistics.  The graph test above runs on ~200 faces, where none of those routes is active."""
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    gt, noisy, smooth, data = _case(dev, "torus144k")
+    runs = []
+    for timed in (False, True):
+        torch.manual_seed(5)
+        posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=1, bnf_start_epoch=2, use_graph=timed, overlap=timed)
+        losses = [tr.step().item() for _ in range(4)]
+        torch.cuda.synchronize()
+        if dtype == torch.float32:
+            assert tr.neng.n_rows >= 65536 and sum(tr.neng.fuse_bnbwd) >= 4 and tr.neng._tail_fused, "not the bench's routes"
+        runs.append((losses, tr.pos.clone(), tr.norm.clone(), posnet.arena.data.clone(), normnet.arena.data.clone(),
+                     tr.lossbuf.clone(), [r.clone() for r in normnet._engine.running],
+                     [r.clone() for r in posnet._engine.running]))
+        del tr, posnet, normnet
+    a, b = runs
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y in zip(a[1:6], b[1:6]):
+        assert torch.equal(x, y)
+    for ra, rb in ((a[6], b[6]), (a[7], b[7])):
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    assert a[5][3] > 0                                     # the gate did open
+    assert all(np.isfinite(a[0]))
 
 
 @pytest.mark.parametrize("which,dtype", [("grid", torch.float32), ("grid", torch.bfloat16), ("torus48k", torch.float32)])
