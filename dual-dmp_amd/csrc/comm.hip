@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -81,6 +82,10 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(const uint4* __restrict_
 struct ddmp_comm {
     nccl_comm comm;
     int rank, world;
+    // DDMP_COMM_LOOPBACK=1 (read at creation): a communicator of ONE rank still goes through RCCL -- every exchange sends and
+    // receives 256 bytes to / from itself inside the group and all-reduces over its one rank -- so that the send/recv symbol
+    // table, the grouped launch and the capture of the partitioned iteration into a hipGraph can be exercised on a one-GPU box
+    char* loop = nullptr;                    // device: 256 bytes out + 256 bytes in
 };
 struct ddmp_halo_plan {
     int world, rank;
@@ -111,13 +116,17 @@ extern "C" int ddmp_comm_create(int rank, int world, const char* id128_host, ddm
     std::copy(id128_host, id128_host + 128, id.internal);
     nccl_comm c = nullptr;
     NCCL_TRY(rccl().CommInitRank(&c, world, id, rank));
-    *out = new ddmp_comm{c, rank, world};
+    ddmp_comm* cm = new ddmp_comm{c, rank, world};
+    const char* lb = getenv("DDMP_COMM_LOOPBACK");
+    if (world == 1 && lb && atoi(lb) == 1 && hipMalloc((void**)&cm->loop, 512) == hipSuccess) (void)hipMemset(cm->loop, 0, 512);
+    *out = cm;
     return DDMP_OK;
 }
 
 extern "C" int ddmp_comm_destroy(ddmp_comm* c) {
     if (!c) return DDMP_OK;
     if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->loop) (void)hipFree(c->loop);
     delete c;
     return DDMP_OK;
 }
@@ -189,7 +198,7 @@ extern "C" int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* p, void
                            (const uint4*)T, ld * es / 16, p->send_idx, p->n_send, q, (uint4*)pack_ws);
         LAUNCH_TRY();
     }
-    if (comm->world == 1 && n_sums == 0) return DDMP_OK;
+    if (comm->world == 1 && n_sums == 0 && !comm->loop) return DDMP_OK;
     Rccl& R = rccl();
     NCCL_TRY(R.GroupStart());
     // Inside the group nothing returns early: a return between GroupStart and GroupEnd would leave every later RCCL call
@@ -205,6 +214,10 @@ extern "C" int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* p, void
         soff += ns;
         roff += nr;
     }
+    if (comm->loop && !err) {                                    // (one rank: to and from itself)
+        err = R.Send(comm->loop, 256, kNcclInt8, 0, comm->comm, st);
+        if (!err) err = R.Recv(comm->loop + 256, 256, kNcclInt8, 0, comm->comm, st);
+    }
     if (n_sums > 0 && !err) err = R.AllReduce(sums, sums, (size_t)n_sums, kNcclFloat64, kNcclSum, comm->comm, st);
     const int end = R.GroupEnd();
     if (err) return 1000 + err;
@@ -214,7 +227,7 @@ extern "C" int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* p, void
 
 extern "C" int ddmp_comm_allreduce_sum(ddmp_comm* comm, void* buf, int64_t n, int is_f64, ddmp_stream stream) {
     ARG_TRY(comm && buf && n > 0);
-    if (comm->world == 1) return DDMP_OK;
+    if (comm->world == 1 && !comm->loop) return DDMP_OK;
     NCCL_TRY(rccl().AllReduce(buf, buf, (size_t)n, is_f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, comm->comm, (hipStream_t)stream));
     return DDMP_OK;
 }

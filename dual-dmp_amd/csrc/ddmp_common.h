@@ -106,16 +106,8 @@ namespace ddmp {
 constexpr int kChunkRows = 64;
 // LDS-patch SpMM (spmm_patch.hip), shared by the float32 and bfloat16 entry points: DDMP_OK / an error / "take the slab kernel"
 constexpr int kPatchNotApplicable = -100;
-// Measured 1.6x slower than the slab / lean kernels: NOT part of the default library.  `make EXPERIMENTAL=1`
-// compiles experimental/spmm_patch.hip in (A/B runs with DDMP_SPMM_PATCH=1); without it every call takes the slab kernel.
-#ifdef DDMP_WITH_SPMM_PATCH
+// spmm_patch.hip: the caller takes its slab / lean kernel when this returns kPatchNotApplicable (selection: patch_mode there)
 int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
                const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
                const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st);
-#else
-inline int spmm_patch(const ddmp_graph*, const void*, int64_t, void*, int64_t, int, int, const float*, const float*, const float*,
-                      float, const void*, int64_t, const float*, const float*, const float*, const float*, float*, hipStream_t) {
-    return kPatchNotApplicable;
-}
-#endif
 }

@@ -1005,10 +1005,9 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     return DDMP_OK;
 }
 
-// The wide f16x3 wgrad: row-major staging kernel of round 4 (gemm_tn_rm.hip); DDMP_TN_RM=0 keeps the round-3 panel kernel (A/B)
-static bool tn_rm_enabled() {
-    static const bool e = [] { const char* v = getenv("DDMP_TN_RM"); return !(v && atoi(v) == 0); }();
-    return e;
+// The wide f16x3 wgrad: row-major staging kernel of round 4 (gemm_tn_rm.hip).  Row strides as 32-bit byte counts.
+static inline bool tn_wide_ok(int64_t ld0, int64_t ld1, int64_t ld2) {
+    return ld0 * 4 < ((int64_t)1 << 31) && ld1 * 4 < ((int64_t)1 << 31) && ld2 * 4 < ((int64_t)1 << 31);
 }
 static void launch_tn_wide(const float* G, int64_t ldg, const float* G2, int64_t ldg2, const float* Z, int64_t ldz, float* part,
                            int64_t sstride, int64_t n_rows, int M, int K, const TnPlan& p, const float* ps, const float* psh,
@@ -1056,7 +1055,7 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
                        p.n_splits, pro_scale, pro_shift, (const float*)nullptr, (const float*)nullptr,           \
                        (const float*)nullptr, (const float*)nullptr, slope, gslot, zslot, target, heal_)
         const int mode_ = gemm_mode();
-        if (mode_ == 6 && gemm_f16()) {
+        if (mode_ == 6 && gemm_f16() && tn_wide_ok(ldg, 0, ldz)) {
             float* tail = (float*)((char*)workspace + need - 64);
             const bool own = !(ctx.a && ctx.b);
             gslot = own ? tail : ctx.a;
@@ -1068,17 +1067,9 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
                 if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
                 else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
             }
-            const bool rm = tn_rm_enabled() && ldg * 4 < (int64_t)1 << 31 && ldz * 4 < (int64_t)1 << 31;
-            for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {      // second launch: redo on overflow (gemm_f16s.inc)
-                if (rm) {
-                    launch_tn_wide(G, ldg, nullptr, 0, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, nullptr, nullptr,
-                                   nullptr, nullptr, slope, gslot, zslot, target, heal_, st);
-                } else if (pro_scale) {
-                    DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, false>));
-                } else {
-                    DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, false>));
-                }
-            }
+            for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_)        // second launch: redo on overflow (gemm_f16s.inc)
+                launch_tn_wide(G, ldg, nullptr, 0, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, nullptr, nullptr,
+                               nullptr, nullptr, slope, gslot, zslot, target, heal_, st);
             heal_ = 0;
         } else if (pro_scale) {
             if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, false>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, false>));
@@ -1236,7 +1227,8 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
                        (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale,       \
                        pro_shift, a, b, c1, c0, slope, gslot, zslot, target, heal_)
     const int mode_ = gemm_mode();
-    if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0) {
+    if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0 && tn_wide_ok(lddz, ldyb, ldz) &&
+        aligned16(dZ) && aligned16(Yb) && aligned16(Z)) {
         float* tail = (float*)((char*)workspace + need - 64);
         const bool own = !(ctx.a && ctx.b);
         gslot = own ? tail : ctx.a;
@@ -1248,18 +1240,9 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
             if (pro_scale) f16s_measure<1>(Z, ldz, nullptr, 0, n_rows, K, pro_scale, pro_shift, nullptr, nullptr, slope, zslot, st);
             else f16s_measure<0>(Z, ldz, nullptr, 0, n_rows, K, nullptr, nullptr, nullptr, nullptr, slope, zslot, st);
         }
-        const bool rm = tn_rm_enabled() && lddz * 4 < (int64_t)1 << 31 && ldyb * 4 < (int64_t)1 << 31 && ldz * 4 < (int64_t)1 << 31 &&
-                        aligned16(dZ) && aligned16(Yb) && aligned16(Z);
-        for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_) {          // second launch: redo on overflow (gemm_f16s.inc)
-            if (rm) {
-                launch_tn_wide(dZ, lddz, Yb, ldyb, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, a, b, c1, c0, slope,
-                               gslot, zslot, target, heal_, st);
-            } else if (pro_scale) {
-                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, true, true>));
-            } else {
-                DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<13, false, true>));
-            }
-        }
+        for (heal_ = 0; heal_ <= (prime ? 0 : 1); ++heal_)            // second launch: redo on overflow (gemm_f16s.inc)
+            launch_tn_wide(dZ, lddz, Yb, ldyb, Z, ldz, part, sstride, n_rows, M, K, p, pro_scale, pro_shift, a, b, c1, c0, slope,
+                           gslot, zslot, target, heal_, st);
         heal_ = 0;
     } else if (pro_scale) {
         if (mode_ == 6) DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<3, true, true>)); else DDMP_LAUNCH_TNP((gemm_tn_panel_kernel<2, true, true>));

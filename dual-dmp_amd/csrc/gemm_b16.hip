@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -397,13 +398,18 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
         }
     }
     uint4 rg[2][2], rz[2][2], rg2[GDUAL ? 2 : 1][2];             // [slot][pass]
+    // Round 4: the loads are UNCONDITIONAL (columns beyond M / K are clamped to valid ones and zeroed at the store).  As
+    // `on ? load : 0` every load sat in an exec-masked block of its own: no interleaving with the MFMAs and, since the compiler
+    // cannot count loads across a block that may be skipped, vmcnt(0) before the uses (the float32 wgrad had the same disease:
+    // profiles/r04_tn_ablation.txt).
+    const int gcol_c = min(gcol, M - 8), zcol_c = min(zcol, K - 8);
     auto load = [&](int sl, int r0) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int64_t row = min(r0 + p * 16 + sr, r_end - 1);
-            rg[sl][p] = g_on ? ld8b(G + row * ldg + gcol) : make_uint4(0, 0, 0, 0);
-            if constexpr (GDUAL) rg2[sl][p] = g_on ? ld8b(G2 + row * ldg2 + gcol) : make_uint4(0, 0, 0, 0);
-            rz[sl][p] = z_on ? ld8b(Z + row * ldz + zcol) : make_uint4(0, 0, 0, 0);
+            rg[sl][p] = ld8b(G + row * ldg + gcol_c);
+            if constexpr (GDUAL) rg2[sl][p] = ld8b(G2 + row * ldg2 + gcol_c);
+            rz[sl][p] = ld8b(Z + row * ldz + zcol_c);
         }
     };
     auto store = [&](int buf, int sl, int r0) {
@@ -420,14 +426,15 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
                     x[e] = fmaf(ca[e], x[e] * lrelu_grad(fmaf(y[e], ca[e], cb[e]), slope), fmaf(ck1[e], y[e], ck0[e]));
                 g = g_on ? bf_pack8(x) : make_uint4(0, 0, 0, 0);
             }
-            if (r0 + r >= r_end) g = make_uint4(0, 0, 0, 0);     // rows beyond the split contribute nothing
+            if (r0 + r >= r_end || !g_on) g = make_uint4(0, 0, 0, 0);     // rows beyond the split / columns beyond M contribute nothing
             if (ZPRO) {
                 float f[8];
                 bf_unpack8(z, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = lrelu(fmaf(f[e], pa[e], pb[e]), slope);
-                z = z_on ? bf_pack8(f) : make_uint4(0, 0, 0, 0);
+                z = bf_pack8(f);
             }
+            if (!z_on) z = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4*>(&Gs[buf][tn_off(r, sc8 * 8)]) = g;
             *reinterpret_cast<uint4*>(&Zs[buf][tn_off(r, sc8 * 8)]) = z;
         }
@@ -455,8 +462,8 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
         o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
         return o;
     };
-    auto compute = [&](int buf) {
-        if (!wave_on) return;
+    auto compute = [&](int buf, auto on) __attribute__((always_inline)) {
+        if (!decltype(on)::value) return;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[2], bf[4];
@@ -480,21 +487,29 @@ __global__ __launch_bounds__(512) void gemm_tn_b16_kernel(
     }
     lds_barrier();
     // iteration s (LDS buffer s & 1): slot (s+1) & 1 holds stage s+1; it is stored into the other buffer and refilled with
-    // stage s+3
+    // stage s+3.  The loop body is ONE basic block (pairs of iterations, no test inside; `wave_on` -- a wave without a tile in
+    // a narrow panel -- chosen outside): MFMAs, conversions and loads interleave and the vmcnt counts are exact.
+    auto run = [&](auto on) __attribute__((always_inline)) {
+        int s = 0;
 #pragma unroll 1
-    for (int s = 0; s < ns; s += 2) {
-        const int r1 = r_begin + (s + 1) * kBK;
-        compute(0);
-        store(1, 1, r1);
-        load(1, r1 + 2 * kBK);
-        lds_barrier();
-        if (s + 1 < ns) {
-            compute(1);
+        for (; s + 1 < ns; s += 2) {
+            const int r1 = r_begin + (s + 1) * kBK;
+            compute(0, on);
+            store(1, 1, r1);
+            load(1, r1 + 2 * kBK);
+            lds_barrier();
+            compute(1, on);
             store(0, 0, r1 + kBK);
             load(0, r1 + 3 * kBK);
+            lds_barrier();
         }
-        lds_barrier();
-    }
+        if (s < ns) {
+            compute(0, on);
+            lds_barrier();
+        }
+    };
+    if (wave_on) run(std::true_type());
+    else run(std::false_type());
 
     if (!wave_on) return;
     float* o = out + (int64_t)split * split_stride;

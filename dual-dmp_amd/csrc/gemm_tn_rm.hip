@@ -58,7 +58,7 @@ __device__ __forceinline__ void lds_barrier() {                  // LDS traffic 
 #endif
 #define DDMP_FENCE_() __builtin_amdgcn_sched_barrier(0)
 
-// PP: the two waves of a SIMD run the segments of an iteration in opposite order (see `iteration`)
+// PP = 1: the two waves of a SIMD run the segments of an iteration in opposite order (see run_dm / run_md)
 template <bool PRO, bool GDUAL, int PP>
 __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 Gs[2][2][kPlane];          // [buffer][term]
@@ -135,25 +135,41 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
         return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
 
+    // Register slots of raw rows.  G (and G2) run TWO stages ahead of their conversion; Z too, except in the three-stream
+    // form (ZL = 1: one stage ahead, 8 registers fewer -- with all three streams two stages ahead hipcc runs out of registers
+    // in the rotated loop and copies slot registers whose loads are in flight, behind a vmcnt(0)).
+    constexpr int ZL = GDUAL ? 1 : 2;
     struct Slot {
-        float4 g[2], z[2], g2[GDUAL ? 2 : 1];
+        float4 g[2], z[ZL == 2 ? 2 : 1], g2[GDUAL ? 2 : 1];
     };
     Slot S[2];
+    float4 Z1[2];                                                // ZL = 1: the one Z slot
+    auto load_z = [&](float4 (&z)[2], int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned rc = (unsigned)min(wave + stage * kRows + 8 * p, r_last);
+            z[p] = ldrow(Zd, voff_z, rc * ldz4);
+            DDMP_FENCE_();
+        }
+    };
     auto load = [&](Slot& sl, int stage) __attribute__((always_inline)) {
+        // (ZL = 1: Z of stage - 1, FIRST -- it is needed one iteration from now, before this call's G rows: the in-order
+        //  counter then lets those stay in flight)
+        if (ZL == 1) load_z(Z1, max(stage - 1, 0));
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const unsigned rc = (unsigned)min(wave + stage * kRows + 8 * p, r_last);        // scalar
-            // (fences: the loads keep THIS order everywhere.  The wait the compiler puts in front of a slot's first use has to
-            // hold on every path into the loop; with the prologue's loads scheduled in another order than the loop's it fell
-            // back to vmcnt(0))
+            // (fences: the loads keep THIS order everywhere)
             sl.g[p] = ldrow(Gd, voff_g, rc * ldg4);
             DDMP_FENCE_();
             if (GDUAL) {
                 sl.g2[GDUAL ? p : 0] = ldrow(G2d, voff_g, rc * ldg24);
                 DDMP_FENCE_();
             }
-            sl.z[p] = ldrow(Zd, voff_z, rc * ldz4);
-            DDMP_FENCE_();
+            if (ZL == 2) {
+                sl.z[ZL == 2 ? p : 0] = ldrow(Zd, voff_z, rc * ldz4);
+                DDMP_FENCE_();
+            }
         }
     };
     // v = the operand times its scale.  No clamp to the f16 range: with a stale scale an element may overflow to inf, but then
@@ -198,12 +214,13 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
         }
     };
     auto store_z = [&](int buf, const Slot& sl) __attribute__((always_inline)) {
+        const float4* zsrc = ZL == 2 ? sl.z : Z1;
         int co = c4;
         asm volatile("" : "+v"(co));
         __builtin_assume((co & 3) == 0);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            float4 x = sl.z[p];
+            float4 x = zsrc[p];
             if (PRO) {
                 const float4 sc = *reinterpret_cast<const float4*>(&s_co[kCoZ][co]);
                 const float4 sh = *reinterpret_cast<const float4*>(&s_co[kCoZ + (PRO ? 1 : 0)][co]);
@@ -340,23 +357,30 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             asm volatile("" ::"v"(sl.g[p].x), "v"(sl.g[p].y), "v"(sl.g[p].z), "v"(sl.g[p].w));
-            asm volatile("" ::"v"(sl.z[p].x), "v"(sl.z[p].y), "v"(sl.z[p].z), "v"(sl.z[p].w));
+            if (ZL == 2) asm volatile("" ::"v"(sl.z[ZL == 2 ? p : 0].x), "v"(sl.z[ZL == 2 ? p : 0].y), "v"(sl.z[ZL == 2 ? p : 0].z), "v"(sl.z[ZL == 2 ? p : 0].w));
             if (GDUAL) asm volatile("" ::"v"(sl.g2[GDUAL ? p : 0].x), "v"(sl.g2[GDUAL ? p : 0].y), "v"(sl.g2[GDUAL ? p : 0].z), "v"(sl.g2[GDUAL ? p : 0].w));
         }
     };
     if (ns > 0) {
         load(S[0], 0);
-        load(S[1], 1);
-        store_g(0, S[0], 0);
-        store_z(0, S[0]);
-        load(S[0], 2);
+        if (ZL == 2) {
+            load(S[1], 1);
+            store_g(0, S[0], 0);
+            store_z(0, S[0]);
+            load(S[0], 2);
+        } else {                                                 // (load(S, stage) also requests Z of stage - 1 into Z1)
+            store_g(0, S[0], 0);
+            store_z(0, S[0]);                                    // Z1 = stage 0
+            load(S[1], 1);                                       // G of stage 1; Z1 <- stage 0 again (harmless)
+            load(S[0], 2);                                       // G of stage 2; Z1 <- stage 1
+        }
         // The loops are entered with NO load pending as far as the compiler knows: the wait it puts in front of a slot's first
         // use has to hold on every path into the loop, and against the prologue's pending loads (other registers, other order)
         // it came out as vmcnt(0) in every iteration.  One drain per kernel instead.
         settle(S[1]);
         settle(S[0]);
         lds_barrier();
-        if (PP == 1 ? wave < 4 : PP == 2 ? (wave & 1) == 0 : PP == 3 ? (wave & 2) == 0 : false) run_md();      // (uniform)
+        if (PP == 1 && wave < 4) run_md();                       // (uniform; waves w and w + 4 share a SIMD)
         else run_dm();
     }
 
@@ -388,14 +412,15 @@ void launch_tn_rm(const TnRmArgs& a, hipStream_t st) {
     const int n_tiles = a.n_tiles_m * a.n_tiles_k;
     dim3 grid((unsigned)(cdiv(a.n_splits, kXcd) * kXcd * n_tiles)), block(512);
     const bool pro = a.pscale != nullptr, gdual = a.G2 != nullptr;
-    static const int pp = [] { const char* e = getenv("DDMP_TN_PP"); return e ? atoi(e) : 0; }();      // (A/B)
+    // DDMP_TN_PP=0: the same segment order on all waves (A/B; measured 6-9 % slower: profiles/r04_tn_kernel_ab.txt)
+    static const int pp = [] { const char* e = getenv("DDMP_TN_PP"); return e ? atoi(e) : 1; }();
 #define DDMP_L_(P_, G_, Q_) hipLaunchKernelGGL((gemm_tn_rm_kernel<P_, G_, Q_>), grid, block, 0, st, a)
 #define DDMP_LQ_(Q_)                                                                              \
     do {                                                                                          \
         if (gdual) { if (pro) DDMP_L_(true, true, Q_); else DDMP_L_(false, true, Q_); }           \
         else { if (pro) DDMP_L_(true, false, Q_); else DDMP_L_(false, false, Q_); }               \
     } while (0)
-    if (pp == 1) DDMP_LQ_(1); else if (pp == 2) DDMP_LQ_(2); else if (pp == 3) DDMP_LQ_(3); else DDMP_LQ_(0);
+    if (pp == 0) DDMP_LQ_(0); else DDMP_LQ_(1);
 #undef DDMP_LQ_
 #undef DDMP_L_
 }

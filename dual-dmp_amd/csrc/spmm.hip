@@ -150,142 +150,6 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
-//  Patch-staged variant (C >= 32).  With nodes numbered along a space-filling curve (engine.py relabels by
-//  Morton order) RB consecutive rows form a compact 2-D patch of the mesh whose neighbours are mostly inside
-//  the patch.  The row kernel above reads every neighbour row through L2 (7 row reads per output row on the
-//  vertex graph: measured ~11 TB/s of L2 traffic, i.e. L2-bandwidth-bound at 34-50 % of the HBM roofline).
-//  Here a workgroup stages its RB x CS feature tile in LDS ONCE (coalesced, prologue applied once per element
-//  instead of once per gather), in-patch neighbours are read from LDS and only the perimeter goes to L2.
-// ------------------------------------------------------------------------------------------------
-template <int RB, int CS, bool PRO>
-__global__ __launch_bounds__(256) void spmm_patch_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
-    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows,
-    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int per_xcd, int n_chunks, int n_slabs) {
-    constexpr int LANES = CS / 4;              // lanes per row
-    constexpr int RPW = 64 / LANES;            // rows per wave step
-    constexpr int RPB = 4 * RPW;               // rows per block step
-    constexpr int MAXE = RB * 10;
-    __shared__ __attribute__((aligned(16))) float tile[RB * CS];
-    __shared__ int s_rowptr[RB + 1];
-    __shared__ int s_col[MAXE];
-    __shared__ float s_w[MAXE];
-
-    const int lin = (blockIdx.x & (kXcd - 1)) * per_xcd + (blockIdx.x >> 3);
-    const int chunk = lin / n_slabs, slab = lin % n_slabs;
-    if (chunk >= n_chunks) return;
-    const int r0 = chunk * RB, c0 = slab * CS;
-    const int nr = min(RB, n_rows - r0);
-    const int tid = threadIdx.x;
-
-    for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
-    // feature tile: thread -> (column quad, row), fixed column per thread
-    const int tq = tid % LANES, tr = tid / LANES;
-    float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (PRO) {
-        pa = *reinterpret_cast<const float4*>(pscale + c0 + tq * 4);
-        pb = *reinterpret_cast<const float4*>(pshift + c0 + tq * 4);
-    }
-#pragma unroll 4
-    for (int r = tr; r < nr; r += 256 / LANES) {
-        float4 v = *reinterpret_cast<const float4*>(X + (int64_t)(r0 + r) * ldx + c0 + tq * 4);
-        if (PRO) v = f4_affine_lrelu(v, pa, pb, slope);
-        *reinterpret_cast<float4*>(&tile[r * CS + tq * 4]) = v;
-    }
-    __syncthreads();
-    const int e0 = s_rowptr[0];
-    const int ne = s_rowptr[nr] - e0;
-    const bool staged = ne <= MAXE;
-    if (staged) {
-        for (int t = tid; t < ne; t += 256) {
-            const int c = col[e0 + t];
-            s_col[t] = c;
-            s_w[t] = dinv[c];
-        }
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int grp = lane / LANES, sl = lane % LANES;
-    float4 qa = pa, qb = pb;
-    if (PRO) {                                  // prologue constants of THIS lane's gather columns
-        qa = *reinterpret_cast<const float4*>(pscale + c0 + sl * 4);
-        qb = *reinterpret_cast<const float4*>(pshift + c0 + sl * 4);
-    }
-    const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + c0 + sl * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* xcol = X + c0 + sl * 4;
-
-    for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
-        const int es = s_rowptr[lr] - e0, ee = s_rowptr[lr + 1] - e0;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = es; e < ee; e += 4) {
-            int cj[4];
-            float wj[4];
-            float4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ek = min(e + k, ee - 1);
-                if (staged) {
-                    cj[k] = s_col[ek];
-                    wj[k] = s_w[ek];
-                } else {
-                    cj[k] = col[e0 + ek];
-                    wj[k] = dinv[cj[k]];
-                }
-                if (e + k >= ee) wj[k] = 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                       // perimeter: L2 / HBM
-                const unsigned loc = (unsigned)(cj[k] - r0);
-                if (loc >= (unsigned)nr) {
-                    float4 t = *reinterpret_cast<const float4*>(xcol + (int64_t)cj[k] * ldx);
-                    if (PRO) t = f4_affine_lrelu(t, qa, qb, slope);
-                    v[k] = t;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                       // interior: LDS
-                const unsigned loc = (unsigned)(cj[k] - r0);
-                if (loc < (unsigned)nr) v[k] = *reinterpret_cast<const float4*>(&tile[loc * CS + sl * 4]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                acc.x = fmaf(wj[k], v[k].x, acc.x);
-                acc.y = fmaf(wj[k], v[k].y, acc.y);
-                acc.z = fmaf(wj[k], v[k].z, acc.z);
-                acc.w = fmaf(wj[k], v[k].w, acc.w);
-            }
-        }
-        const int row = r0 + lr;
-        const float di = dinv[row];
-        float4 o;
-        o.x = fmaf(acc.x, di, bs.x);
-        o.y = fmaf(acc.y, di, bs.y);
-        o.z = fmaf(acc.z, di, bs.z);
-        o.w = fmaf(acc.w, di, bs.w);
-        nt_store4(Y + (int64_t)row * ldy + c0 + sl * 4, o);
-    }
-}
-
-template <int RB, int CS>
-int launch_patch(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
-                 const float* ps, const float* psh, float slope, hipStream_t st) {
-    const int n = (int)g->n_rows;
-    const int n_chunks = (int)cdiv(n, RB), n_slabs = C / CS;
-    const int per_xcd = (int)cdiv((int64_t)n_chunks * n_slabs, kXcd);
-    dim3 grid(per_xcd * kXcd), block(256);
-    if (ps)
-        hipLaunchKernelGGL((spmm_patch_kernel<RB, CS, true>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                           Y, ldy, n, bias, ps, psh, slope, per_xcd, n_chunks, n_slabs);
-    else
-        hipLaunchKernelGGL((spmm_patch_kernel<RB, CS, false>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                           Y, ldy, n, bias, ps, psh, slope, per_xcd, n_chunks, n_slabs);
-    LAUNCH_TRY();
-    return DDMP_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 //  Slab-looping variant (C >= 64): same chunk ownership and LDS-staged CSR slice as the row kernel, but the
 //  workgroup walks its rows one SLAB of CS channels at a time (CS*4 = 128 or 256 bytes = 1-2 cache lines per
 //  row) and loops over the C/CS slabs itself.  Measured on the row kernel (rocprofv3 PMC, 1M-face mesh, Morton
@@ -571,8 +435,7 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
     static int spmm_mode = -1;                       // DDMP_SPMM=row selects the row kernel for every width
     if (spmm_mode < 0) {
         const char* e = getenv("DDMP_SPMM");
-        spmm_mode = (e && e[0] == 'r') ? 0 : (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3
-                    : (e && e[0] == 's' && e[1] == '1') ? 5 : 4;          // default: slab kernel, 32-channel slabs
+        spmm_mode = (e && e[0] == 'r') ? 0 : (e && e[0] == 's' && e[1] == '1') ? 5 : 4;      // default: slab / lean kernels
     }
     if (vec && spmm_mode >= 4) {                                 // LDS-patch kernel (spmm_patch.hip) where it applies
         const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
@@ -594,18 +457,6 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
         if (spmm_mode == 4) return launch_slab<8, 4, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
         if (g->max_row_nnz <= 4) return launch_slab<8, 4, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
         return launch_slab<8, 8, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-    } else if (vec && spmm_mode != 0) {
-        if (spmm_mode == 1) {
-            if (C == 32) return launch_patch<128, 32>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-            if (C >= 64 && C % 64 == 0) return launch_patch<128, 64>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        } else if (spmm_mode == 2) {
-            if (C == 32) return launch_patch<256, 32>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-            if (C >= 64 && C % 64 == 0) return launch_patch<256, 64>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        } else {
-            if (C == 32) return launch_patch<128, 32>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-            if (C == 64) return launch_patch<128, 64>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-            if (C >= 128 && C % 128 == 0) return launch_patch<128, 128>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        }
     }
     if (vec) {
         switch (C) {

@@ -267,133 +267,6 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round-3 prototype (DDMP_SPMM_PATCH=2): wave-private DMA gathers, no de-duplication, no barrier in the slab loop.
-// The counters of the lean kernel (profiles/r03_gather_tcp_tcc_counters.txt) show the L1 active for the whole kernel and
-// stalled on its data return to the registers for 39-54 % of those cycles.  Here a gathered piece never returns to a
-// register from memory: a wave copies the E entry slots of its 8 rows with E global_load_lds_dwordx4 (one 128-byte piece
-// per 8-lane group and instruction) into a private LDS buffer, NBUF - 1 work items (row step x slab) ahead, waits on the
-// counted VMEM counter and reads the pieces back with ds_read_b128.  float32, plain | prologue forms.
-template <int E, int NBUF, bool PRO>
-__global__ __launch_bounds__(256) void spmm_dma_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
-    const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
-    const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
-    int chunks_per_xcd, int n_chunks) {
-    static_assert(E == 4 || E == 8, "entry slots per row");
-    constexpr int kBufB = E * 1024;                              // bytes per work item: E pieces x 8 rows x 128 B
-    __shared__ int s_rowptr[kRB + 1];
-    __shared__ float s_di[kRB];
-    __shared__ __attribute__((aligned(16))) uint2 s_ent[kRB * E];    // (row offset in 16-byte units, weight), padded slots
-    __shared__ __attribute__((aligned(16))) unsigned char s_buf[4 * NBUF * kBufB];
-
-    const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
-    if (chunk >= n_chunks) return;
-    const int r0 = chunk * kRB;
-    const int nr = min(kRB, n_rows - r0);
-    const int tid = threadIdx.x;
-    for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
-    __syncthreads();
-    const unsigned ld16 = (unsigned)(ldx >> 2);
-    for (int i = tid; i < kRB * E; i += 256) {
-        const int lr = min(i / E, nr - 1), k = i % E;
-        const int rb = s_rowptr[lr], nn = s_rowptr[lr + 1] - rb;
-        uint2 e = make_uint2(0u, 0u);
-        if (nn > 0) {
-            const int c = col[rb + min(k, nn - 1)];
-            e.x = (unsigned)c * ld16;
-            e.y = (k < nn && i / E < nr) ? __float_as_uint(dinv[c]) : 0u;
-        }
-        s_ent[i] = e;
-        if (k == 0) s_di[i / E] = dinv[r0 + lr];
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = lane >> 3, sl = lane & 7;
-    unsigned char* wbuf = s_buf + wave * (NBUF * kBufB);
-    const int n_slabs = C / 32, n_items = n_slabs * 2;           // item = (slab, row step q): rows wave * 8 + grp + 32 q
-    // this lane's E source offsets per row step (16-byte units, without the slab): registers, 2 x E
-    unsigned off[2][E];
-    float w[2][E];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const uint2 e = s_ent[(wave * 8 + grp + 32 * q) * E + k];
-            off[q][k] = e.x;
-            w[q][k] = __uint_as_float(e.y);
-        }
-    const char* xb = reinterpret_cast<const char*>(X + sl * 4);
-    auto issue = [&](int item, int b) {
-        const int s = item >> 1, q = item & 1;
-        const char* base = xb + (size_t)s * 128;
-#pragma unroll
-        for (int k = 0; k < E; ++k) dma16(base + ((uint64_t)(q ? off[1][k] : off[0][k]) << 4), wbuf + b * kBufB + k * 1024);
-    };
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i)
-        if (i < n_items) issue(i, i);
-    int b = 0;
-    for (int item = 0; item < n_items; ++item) {
-        if (item + NBUF - 1 < n_items) issue(item + NBUF - 1, (b + NBUF - 1) % NBUF);
-        // VMEM operations younger than this item's copies: (NBUF - 1) x E copies and the NBUF - 1 stores issued since
-        // (fewer near both ends of the item sequence: a full drain there)
-        if (nr == kRB && item >= NBUF - 1 && item + NBUF - 1 < n_items) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * (E + 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int s = item >> 1, q = item & 1;
-        const int c0 = s * 32 + sl * 4;
-        const unsigned char* pb = wbuf + b * kBufB + lane * 16;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 pa = make_float4(1.f, 1.f, 1.f, 1.f), pb4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PRO) {
-            pa = *reinterpret_cast<const float4*>(pscale + c0);
-            pb4 = *reinterpret_cast<const float4*>(pshift + c0);
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            float4 t = *reinterpret_cast<const float4*>(pb + k * 1024);
-            if (PRO) t = f4_affine_lrelu(t, pa, pb4, slope);
-            const float wk = q ? w[1][k] : w[0][k];
-            acc.x = fmaf(wk, t.x, acc.x);
-            acc.y = fmaf(wk, t.y, acc.y);
-            acc.z = fmaf(wk, t.z, acc.z);
-            acc.w = fmaf(wk, t.w, acc.w);
-        }
-        const int lr = wave * 8 + grp + 32 * q;
-        const float di = s_di[min(lr, nr - 1)];
-        const float4 bs = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 o4;
-        o4.x = fmaf(acc.x, di, bs.x);
-        o4.y = fmaf(acc.y, di, bs.y);
-        o4.z = fmaf(acc.z, di, bs.z);
-        o4.w = fmaf(acc.w, di, bs.w);
-        // (always one store per item and lane, so that the counts above hold: rows past the chunk's end re-store row nr - 1's slot... of THEIR OWN lane group -- harmless duplicates of a valid row)
-        float* dst = Y + (int64_t)(r0 + min(lr, nr - 1)) * ldy + c0;
-        if (lr < nr) nt_store4(dst, o4);
-        else asm volatile("s_nop 0" ::: "memory");
-        b = b + 1 == NBUF ? 0 : b + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <int E, int NBUF>
-int launch_dma(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C, const float* bias,
-               const float* ps, const float* psh, float slope, hipStream_t st) {
-    const int n = (int)g->n_rows;
-    const int n_chunks = (int)cdiv(n, kRB);
-    const int cpx = (int)cdiv(n_chunks, kXcd);
-    if (ps)
-        hipLaunchKernelGGL((spmm_dma_kernel<E, NBUF, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                           Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
-    else
-        hipLaunchKernelGGL((spmm_dma_kernel<E, NBUF, false>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                           Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
-    LAUNCH_TRY();
-    return DDMP_OK;
-}
-
 int patch_nb() {                                                  // DDMP_SPMM_PATCH_NB=2|4 (A/B)
     static int nb = 0;
     if (!nb) {
@@ -450,23 +323,31 @@ int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, in
     }
 }
 
-// DDMP_SPMM_PATCH=1 selects this kernel (A/B runs).  OFF by default -- measured on MI355X, 1M-face mesh, Morton order,
-// C = 512 (scripts/microbench.py spmm): float32 face graph 1329 us vs 839 us for the slab kernel, vertex graph 911 vs
-// 592 us; bfloat16 860 vs 452 and 599 vs 332 us (1815 / 1118 us before the copies were hidden from hipcc's waitcnt pass,
-// b16_common.h dma16).  One workgroup of ~110 KB LDS per CU leaves the per-chunk set-up (CSR slice, patch list,
-// coefficients: two block-wide syncs) and the per-slab barrier exposed; at C = 64 the kernel is 2.8x slower.  The slab
-// kernels' 32 waves per CU hide more latency through the L1 than four waves do through LDS.
+// Where this kernel runs (round 4: part of the default library).  Measured on MI355X, 1M-face mesh, float32, two patch buffers
+// (profiles/r03_experiments/spmm_patch_two_buffers.txt): on the FACE graph (4 entries per row) at C >= 256 it moves 5.1-5.2
+// TB/s -- 0.635-0.655 of 8 TB/s, the rate of a device copy -- against 0.575-0.59 for the lean gather (C = 256: 396 vs 450 us,
+// C = 512: 811 vs 840; with the BatchNorm+LeakyReLU prologue 406 vs 460 at C = 256 but 1071 vs 880 at C = 512); it loses at
+// C <= 128, with a fused reduction and on the 7-entry vertex graph.  DDMP_SPMM_PATCH: unset = that selection (float32, <= 5
+// entries per row, plain C >= 256 | prologue 256 <= C < 512), 0 = never, 1 = wherever it applies (A/B runs).
 int patch_mode() {
     static int m = -1;
     if (m < 0) {
         const char* e = getenv("DDMP_SPMM_PATCH");
-        m = e ? atoi(e) : 0;
-        if (m != 1 && m != 2) m = 0;
+        m = e ? atoi(e) : 3;
+        if (m != 0 && m != 1) m = 3;
     }
     return m;
 }
 
 }  // namespace
+
+// does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
+extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red) {
+    if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || g->max_row_nnz > kMaxE / kRB || !g->lcol) return 0;
+    if (patch_mode() == 3 && (dtype != DDMP_F32 || has_red || g->max_row_nnz > 5 || C < 256 || (has_pro && C >= 512))) return 0;
+    const int cs = dtype == DDMP_BF16 ? 64 : 32;
+    return (C % cs == 0 && C >= 2 * cs && C <= 1024) ? 1 : 0;
+}
 
 namespace ddmp {
 
@@ -475,22 +356,7 @@ namespace ddmp {
 int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
                const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
                const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st) {
-    if (patch_mode() == 2) {                                     // wave-private DMA gathers (prototype: float32, plain | prologue)
-        if (dtype != DDMP_F32 || red_part || C % 32 != 0 || C < 64 || g->max_row_nnz > 8 || (ldx & 3) || (ldy & 3) ||
-            (uint64_t)g->n_cols * (uint64_t)(ldx >> 2) >= (1ull << 32))
-            return kPatchNotApplicable;
-        static const int nbuf = [] { const char* e = getenv("DDMP_SPMM_DMA_NBUF"); return e ? atoi(e) : 2; }();
-        auto x = static_cast<const float*>(X);
-        auto y = static_cast<float*>(Y);
-        if (g->max_row_nnz <= 4)
-            return nbuf == 3 ? launch_dma<4, 3>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st)
-                             : launch_dma<4, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st);
-        return nbuf == 3 ? launch_dma<8, 3>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st)
-                         : launch_dma<8, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st);
-    }
-    if (!patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || g->max_row_nnz > kMaxE / kRB || !g->lcol) return kPatchNotApplicable;
-    const int cs = dtype == DDMP_BF16 ? 64 : 32;
-    if (C % cs != 0 || C < 2 * cs || C > 1024) return kPatchNotApplicable;
+    if (!ddmp_spmm_patch_selected(g, C, dtype, ps != nullptr, red_part != nullptr)) return kPatchNotApplicable;
     RedArgs red{red_Yp, red_ldyp, red_scale, red_shift, red_mean, red_rstd, red_part};
     if (dtype == DDMP_BF16) {
         auto x = static_cast<const bf16_t*>(X);

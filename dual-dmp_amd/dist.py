@@ -711,8 +711,13 @@ class DistributedTrainer:
 
     def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
-                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None):
-        """``losses``: "sharded" (every rank evaluates the loss terms of its own rows on a ghost closure; two small
+                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None, use_graph=None):
+        """``use_graph`` (default: env DDMP_DIST_GRAPH=1): replay the partitioned iteration as ONE hipGraph -- every kernel and,
+        with the native RCCL backend, every collective is enqueued on the capturing stream(s) from C (csrc/comm.hip); the Adam
+        step count lives on the device as in FusedTrainer(use_graph=True).  First call eager, second captured, then replayed;
+        re-captured when the BNF gate opens.  Native backend only (torch.distributed's collectives are issued from Python).
+
+        ``losses``: "sharded" (every rank evaluates the loss terms of its own rows on a ghost closure; two small
         all-reduces of partial sums; default on the GPU) or "replicated" (one all-gather of pos | norm, every rank
         runs the whole-mesh losses; what a caller-supplied ``loss_engine`` implies).  Env: DDMP_DIST_LOSSES.
 
@@ -727,6 +732,19 @@ class DistributedTrainer:
         with ctx:
             self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
                        eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
+        import os
+        if use_graph is None:
+            use_graph = os.environ.get("DDMP_DIST_GRAPH", "0") == "1"
+        self.use_graph = bool(use_graph) and isinstance(backend, NativeComm) and torch.device(device).type == "cuda"
+        self._graphs, self._warm = {}, False
+        if self.use_graph:
+            self.interleaved = False
+            # ONE stream under capture: capturing the two-stream form (two RCCL communicators, one per stream, forked and
+            # joined by events) ends in a SIGSEGV inside the capture on ROCm 7.2 (tests/test_gpu_multi.py ran it with
+            # DDMP_COMM_LOOPBACK=1); PosNet keeps its own communicator, on the same stream
+            self.two_streams = False
+            self._t_dev = torch.zeros(1, dtype=torch.int32, device=device)
+            self._coef = [torch.zeros(2, dtype=torch.float32, device=device) for _ in range(2)]
 
     def _init(self, posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas, eps,
               bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos):
@@ -806,8 +824,7 @@ class DistributedTrainer:
 
     def _assemble_full(self):
         """pos | norm of the whole mesh on every rank: ONE all-gather of the owned rows (padded to the largest shard),
-        scattered to their global places.  COLLECTIVE: every rank has to call it (gather_pos / gather_norm / .pos /
-        .norm do) at the same point; cached until the next step."""
+        scattered to their global places.  COLLECTIVE: every rank has to call it (gather_pos / gather_norm do) at the same point; cached until the next step."""
         key = (getattr(self.peng, "n_forward", 0), getattr(self.neng, "n_forward", 0))    # any forward (step, net(data),
         if self._full_epoch == key and self._full is not None:                            # eval) invalidates the cache
             return self._full
@@ -834,10 +851,8 @@ class DistributedTrainer:
         with self.ops.on_device(self.device):
             return self._assemble_full()[self.sd.V: self.sd.V + self.sd.F]
 
-    # Convenience spellings of the two methods above (FusedTrainer has .pos / .norm attributes).  They are COLLECTIVES like
-    # the methods: every rank has to read them at the same point -- `if rank == 0: tr.pos` deadlocks; prefer the methods.
-    pos = property(gather_pos)
-    norm = property(gather_norm)
+    # (no .pos / .norm attributes here: reading them would be a COLLECTIVE -- `if rank == 0: tr.pos` deadlocks; FusedTrainer
+    #  has the attributes, the partitioned trainer the two methods above)
 
     def _sharded_losses(self, pos_loc, norm_loc, gate):
         """Ghost rows of pos / norm from their owners (two grouped exchanges), then this rank's share of the losses."""
@@ -865,12 +880,45 @@ class DistributedTrainer:
             return self._step()
 
     def _step(self):
-        o = self.ops
         self.epoch += 1
         self.t += 1
+        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
+        if not self.use_graph:
+            self.lossbuf = self._iteration(gate, False)
+            return self.lossbuf[5]
+        self._t_dev.fill_(self.t - 1)
+        if not self._warm:                                       # first call: eager (allocates workspaces, primes the scales)
+            self._warm = True
+            self.lossbuf = self._iteration(gate, True)
+            return self.lossbuf[5]
+        g = self._graphs.get(gate)
+        if g is None:
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                cap = self._iteration(gate, True)
+            g = self._graphs[gate] = (graph, cap)
+        g[0].replay()
+        self.peng.n_forward = getattr(self.peng, "n_forward", 0) + 1      # (a replay is a forward: the all-gather cache key)
+        self.neng.n_forward = getattr(self.neng, "n_forward", 0) + 1
+        self.lossbuf = g[1]
+        return self.lossbuf[5]
+
+    def _iteration(self, gate, dev_adam):
+        o = self.ops
         V = self.sd.V
         pa, na = self.posnet.arena.data, self.normnet.arena.data
         pg, ng = self.posnet._grad_arena, self.normnet._grad_arena
+        if dev_adam:
+            o.adam_prepare(self._t_dev, self.pos_lr, self._coef[0], self.betas)
+            self._t_dev -= 1                                                # one counter, two learning rates
+            o.adam_prepare(self._t_dev, self.norm_lr, self._coef[1], self.betas)
+
+        def pos_update():
+            if dev_adam:
+                o.adam_step_dev_(pa, pg, self.m[0], self.v[0], self._coef[0], self.betas, self.eps)
+            else:
+                o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
         # the two nets alternate at their collectives: one net's halo exchange / BatchNorm all-reduce is in flight
         # while the other net's kernels run
         if self.two_streams:
@@ -884,7 +932,6 @@ class DistributedTrainer:
         else:
             self.peng.forward(pa, update_running=True)
             self.neng.forward(na, update_running=True)
-        gate = 0.0 if self.epoch <= self.bnf_start_epoch else 1.0
         if self.losses == "sharded":
             lossbuf, dpos_loc, dnorm_loc = self._sharded_losses(self.peng.result, self.neng.result, gate)
         else:
@@ -899,7 +946,7 @@ class DistributedTrainer:
             with torch.cuda.stream(self._side):                  # PosNet: backward, gradient all-reduce, Adam -- beside NormalNet
                 self.peng.backward(pa, pg, dpos_loc)
                 self.posnet._reduce_grads()
-                o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+                pos_update()
             self.neng.backward(na, ng, dnorm_loc)
             self.normnet._reduce_grads()
         else:
@@ -910,14 +957,17 @@ class DistributedTrainer:
                 self.neng.backward(na, ng, dnorm_loc)
             self.posnet._reduce_grads()
             self.normnet._reduce_grads()
-            o.adam_step_(pa, pg, self.m[0], self.v[0], self.pos_lr, self.t, self.betas, self.eps)
+            pos_update()
         o.grad_sumsq(ng, out=self.sumsq)
-        o.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
-                     clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        if dev_adam:
+            o.adam_step_dev_(na, ng, self.m[1], self.v[1], self._coef[1], self.betas, self.eps,
+                             clip_sumsq=self.sumsq, max_norm=self.grad_crip)
+        else:
+            o.adam_step_(na, ng, self.m[1], self.v[1], self.norm_lr, self.t, self.betas, self.eps,
+                         clip_sumsq=self.sumsq, max_norm=self.grad_crip)
         if self.two_streams:
             self._join()
-        self.lossbuf = lossbuf
-        return lossbuf[5]
+        return lossbuf
 
     def _fork(self):
         ev = torch.cuda.Event()

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,"/root/repo")
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dual_dmp_amd import ops
 dev=torch.device("cuda:0"); n=1000000

@@ -35,7 +35,7 @@ def main():
     hist = []
     for _ in range(steps):
         loss = tr.step().item()
-        hist.append((loss, tr.pos.clone(), tr.norm.clone()))               # .pos / .norm are collective: every rank
+        hist.append((loss, tr.gather_pos().clone(), tr.gather_norm().clone()))       # collectives: every rank calls them
     healed = tr.check_scales()
     ok = True
     if rank == 0:
@@ -70,8 +70,9 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print("world %d, %s, losses=%s, interleave=%s, native=%s, healed=%d: %s" % (
-            world, kind, losses, os.environ.get("DDMP_DIST_INTERLEAVE", "0"), os.environ.get("DDMP_DIST_NATIVE", "0"), healed,
+        print("world %d, %s, losses=%s, interleave=%s, native=%s, loopback=%s, captured=%d, healed=%d: %s" % (
+            world, kind, losses, os.environ.get("DDMP_DIST_INTERLEAVE", "0"), os.environ.get("DDMP_DIST_NATIVE", "0"),
+            os.environ.get("DDMP_COMM_LOOPBACK", "0"), int(bool(getattr(tr, "_graphs", None))), healed,
             "PARITY" if ok else "FAILED"), flush=True)
     sys.exit(int(verdict.item()))
 

@@ -105,7 +105,7 @@ def _rank_run(rank, P, backend, noisy, smooth, data, steps, stub, oracle, result
     out = []
     for _ in range(steps):
         loss = float(tr.step())
-        out.append((loss, tr.pos.clone(), tr.norm.clone()))
+        out.append((loss, tr.gather_pos().clone(), tr.gather_norm().clone()))
     results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone())
 
 
@@ -282,7 +282,7 @@ def _sharded_rank_run(rank, P, backend, noisy, smooth, data, steps, stub, result
     out = []
     for _ in range(steps):
         loss = float(tr.step())
-        out.append((loss, tr.pos.clone(), tr.norm.clone()))
+        out.append((loss, tr.gather_pos().clone(), tr.gather_norm().clone()))
     results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone())
 
 

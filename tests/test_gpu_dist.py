@@ -45,7 +45,7 @@ def test_partitioned_step_matches_single_device(P, kind):
             tr.epoch = 100
             hist = []
             for _ in range(steps):
-                hist.append((tr.step().item(), tr.pos.clone(), tr.norm.clone()))
+                hist.append((tr.step().item(), tr.gather_pos().clone(), tr.gather_norm().clone()))
             results[r] = (hist, tr)
         except BaseException as e:       # noqa: BLE001
             errs.append(e)

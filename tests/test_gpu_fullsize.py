@@ -132,7 +132,7 @@ def test_training_iteration_invariances_at_1m(big):
         try:
             torch.cuda.set_device(0)
             tr = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, backend=comms[r], nets=nets[r])
-            res[r] = (tr.step().item(), tr.pos.clone(), tr.peng.n_rows, tr.peng.n_cols)
+            res[r] = (tr.step().item(), tr.gather_pos().clone(), tr.peng.n_rows, tr.peng.n_cols)
         except BaseException as e:      # noqa: BLE001
             errs.append(e)
             comms[r].s.barrier.abort()
@@ -182,7 +182,7 @@ def test_eight_rank_partition_at_1m_cad_recipe_gate_open(big):
             torch.cuda.set_device(0)
             t = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, backend=comms[r], nets=nets[r], bnfloop=5, k=K)
             t.epoch = 100
-            res[r] = (t.step().item(), t.pos.clone(), t.peng.n_rows, t.peng.n_cols, t.neng.n_rows)
+            res[r] = (t.step().item(), t.gather_pos().clone(), t.peng.n_rows, t.peng.n_cols, t.neng.n_rows)
         except BaseException as e:      # noqa: BLE001
             errs.append(e)
             comms[r].s.barrier.abort()

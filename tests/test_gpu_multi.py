@@ -13,19 +13,30 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("kind,losses,interleave,native,streams", [
-    ("ico4", "sharded", "0", "0", "1"), ("grid", "sharded", "1", "0", "1"), ("ico4", "replicated", "1", "0", "1"),
+@pytest.mark.parametrize("kind,losses,interleave,native,streams,extra", [
+    ("ico4", "sharded", "0", "0", "1", {}), ("grid", "sharded", "1", "0", "1", {}), ("ico4", "replicated", "1", "0", "1", {}),
     # the library's own RCCL communicators (the default backend): PosNet on a second stream with its own communicator, and
     # the single-stream form
-    ("grid", "sharded", "0", "1", "1"), ("ico4", "replicated", "0", "1", "1"), ("grid", "sharded", "0", "1", "0")])
-def test_rccl_ranks_match_single_device(kind, losses, interleave, native, streams):
+    ("grid", "sharded", "0", "1", "1", {}), ("ico4", "replicated", "0", "1", "1", {}), ("grid", "sharded", "0", "1", "0", {}),
+    # round 4: at world size 1 every exchange still goes THROUGH RCCL (DDMP_COMM_LOOPBACK=1: a self send/recv inside the group
+    # and a one-rank all-reduce per exchange), eagerly and with the whole partitioned iteration captured into one hipGraph
+    # (DDMP_DIST_GRAPH=1: eager, capture, replay), on one stream and on two
+    ("grid", "sharded", "0", "1", "0", {"DDMP_COMM_LOOPBACK": "1"}),
+    ("grid", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1"}),
+    ("grid", "sharded", "0", "1", "0", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"}),
+    ("ico4", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"})])
+def test_rccl_ranks_match_single_device(kind, losses, interleave, native, streams, extra):
     n = min(2, torch.cuda.device_count())                   # counting devices does not initialise the GPU in this process
     assert n >= 1
+    if extra and n > 1:
+        pytest.skip("the loopback switch is for one-rank communicators")
     env = dict(os.environ, DDMP_DIST_INTERLEAVE=interleave, DDMP_DIST_NATIVE=native, DDMP_DIST_STREAMS=streams,
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29600 + (os.getpid() + hash((kind, losses, interleave, native, streams))) % 300
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    port = 29600 + (os.getpid() + hash((kind, losses, interleave, native, streams, tuple(sorted(extra))))) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(HERE, "nccl_worker.py"), kind, losses, "3"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", str(port), os.path.join(HERE, "nccl_worker.py"), kind, losses, "4" if extra.get("DDMP_DIST_GRAPH") else "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300 if extra else 600)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "PARITY" in r.stdout, tail
+    if extra.get("DDMP_DIST_GRAPH"):
+        assert "captured=1" in r.stdout, tail
