@@ -729,20 +729,21 @@ class DistributedTrainer:
         # graphs and engines allocate on the CURRENT device (ddmp_graph_create): enter the device context here too
         # (the CPU tests run this class on a torch stand-in of ops: nothing to enter there)
         ctx = ops.on_device(device) if torch.device(device).type == "cuda" else contextlib.nullcontext()
-        with ctx:
-            self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
-                       eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
         import os
         if use_graph is None:
             use_graph = os.environ.get("DDMP_DIST_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and isinstance(backend, NativeComm) and torch.device(device).type == "cuda"
+        if self.use_graph:
+            # ONE communicator on ONE stream under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1
+            # (tests/test_gpu_multi.py): the captured iteration replays correctly with one communicator; with a second
+            # communicator in the same capture it ends in a SIGSEGV (two streams) or never returns (one stream).
+            backend_pos = None
+        with ctx:
+            self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
+                       eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
         self._graphs, self._warm = {}, False
         if self.use_graph:
             self.interleaved = False
-            # ONE stream under capture: capturing the two-stream form (two RCCL communicators, one per stream, forked and
-            # joined by events) ends in a SIGSEGV inside the capture on ROCm 7.2 (tests/test_gpu_multi.py ran it with
-            # DDMP_COMM_LOOPBACK=1); PosNet keeps its own communicator, on the same stream
-            self.two_streams = False
             self._t_dev = torch.zeros(1, dtype=torch.int32, device=device)
             self._coef = [torch.zeros(2, dtype=torch.float32, device=device) for _ in range(2)]
 
@@ -996,8 +997,9 @@ def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnflo
                 # Two communicators driven concurrently on two streams have run at world size 1 only (no multi-GPU box in
                 # the build loop): with peers they are OPT-IN (DDMP_DIST_STREAMS=1) and then have to pass the concurrent
                 # self-check below; the default with peers is one communicator, one stream.
-                if os.environ.get("DDMP_DIST_STREAMS", "1" if world == 1 else "0") != "0":
-                    backend_pos = NativeComm(device)
+                graph = kw.get("use_graph") if kw.get("use_graph") is not None else os.environ.get("DDMP_DIST_GRAPH", "0") == "1"
+                if os.environ.get("DDMP_DIST_STREAMS", "1" if world == 1 else "0") != "0" and not graph:
+                    backend_pos = NativeComm(device)                 # (a captured iteration uses ONE communicator)
             except Exception as e:      # noqa: BLE001  (every rank takes the same branch: RCCL is there for all or none)
                 import warnings
                 warnings.warn("native RCCL backend unavailable (%s): falling back to torch.distributed" % (e,))

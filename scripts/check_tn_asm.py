@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Static audit of gemm_tn_rm_kernel's ISA (csrc/gemm_tn_rm.hip, the wide f16x3 wgrad of round 4).  What broke the round-3
+kernel was invisible in the source: loads in exec-masked side blocks (vmcnt(0) before every use, no interleaving with the
+MFMAs).  For every instantiation this checks the main loops (the basic blocks that branch back to themselves and hold MFMAs):
+  (1) ONE basic block per loop: 48 MFMAs, the stage's buffer loads, fragment reads and LDS writes of two iterations in it --
+      no load sits in a side block;
+  (2) no scratch (spill) traffic in it;
+  (3) no `s_waitcnt vmcnt(0)`: every wait leaves the younger stage's loads in flight.
+    usage: check_tn_asm.py [gemm_tn_rm_dev.s]     (compiles csrc/gemm_tn_rm.hip --cuda-device-only -S if omitted)"""
+import os, re, subprocess, sys, tempfile
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1:
+    asm = sys.argv[1]
+else:
+    asm = os.path.join(tempfile.gettempdir(), "ddmp_gemm_tn_rm_dev.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only",
+                           "-S", os.path.join(root, "dual-dmp_amd", "csrc", "gemm_tn_rm.hip"), "-o", asm], stderr=subprocess.DEVNULL)
+lines = open(asm).read().split("\n")
+starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_tn_rm_kernelILb[01]ELb[01]ELi[01]E.*:", l)]
+n_kernels = problems = 0
+for st in starts:
+    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[st:end]
+    m = re.search(r"gemm_tn_rm_kernelILb([01])ELb([01])ELi([01])E", body[0])
+    pro, gdual, pp = (int(x) for x in m.groups())
+    n_kernels += 1
+    # basic blocks
+    blocks, cur = [], ["entry", []]
+    for l in body[1:]:
+        mm = re.match(r"^(\.LBB\d+_\d+):", l)
+        if mm:
+            blocks.append(cur)
+            cur = [mm.group(1), []]
+        else:
+            t = l.strip()
+            if t and not t.startswith(";") and not t.startswith("."):
+                cur[1].append(t)
+    blocks.append(cur)
+    loops = [(name, ins) for name, ins in blocks
+             if any(re.match(r"s_cbranch_\w+ " + re.escape(name) + r"$", t) for t in ins) and sum("v_mfma" in t for t in ins) > 0]
+    want_loops = 2 if pp else 1
+    tag = "gemm_tn_rm_kernel<PRO=%d, GDUAL=%d, PP=%d>" % (pro, gdual, pp)
+    if len(loops) != want_loops:
+        print("%s: %d self-looping MFMA blocks, expected %d" % (tag, len(loops), want_loops))
+        problems += 1
+    for name, ins in loops:
+        n_mfma = sum("v_mfma" in t for t in ins)
+        n_ld = sum(t.startswith("buffer_load") or t.startswith("global_load") for t in ins)
+        n_scratch = sum(t.startswith("scratch_") for t in ins)
+        waits = [int(x) for t in ins if t.startswith("s_waitcnt") for x in re.findall(r"vmcnt\((\d+)\)", t)]
+        want_ld = 2 * (6 if gdual else 4)
+        bad = []
+        if n_mfma != 48:
+            bad.append("%d MFMAs (48)" % n_mfma)
+        if n_ld != want_ld:
+            bad.append("%d loads (%d)" % (n_ld, want_ld))
+        if n_scratch:
+            bad.append("%d scratch operations" % n_scratch)
+        if any(w == 0 for w in waits):
+            bad.append("vmcnt(0) in the loop: waits %s" % waits)
+        print("%s %s: %d instructions, %d MFMA, %d loads, vmcnt waits %s%s" % (
+            tag, name, len(ins), n_mfma, n_ld, waits, ("   <-- " + "; ".join(bad)) if bad else ""))
+        problems += bool(bad)
+print("kernels audited: %d, problems: %d" % (n_kernels, problems))
+sys.exit(1 if problems or n_kernels != 8 else 0)
