@@ -1005,9 +1005,11 @@ extern "C" int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int
     return DDMP_OK;
 }
 
-// The wide f16x3 wgrad: row-major staging kernel of round 4 (gemm_tn_rm.hip).  Row strides as 32-bit byte counts.
-static inline bool tn_wide_ok(int64_t ld0, int64_t ld1, int64_t ld2) {
-    return ld0 * 4 < ((int64_t)1 << 31) && ld1 * 4 < ((int64_t)1 << 31) && ld2 * 4 < ((int64_t)1 << 31);
+// The wide f16x3 wgrad: row-major staging kernel of round 4 (gemm_tn_rm.hip).  One split of each operand is one buffer
+// descriptor: its bytes (and the offsets of the rows the kernel requests beyond it: up to 3 stages of 16) fit 31 bits.
+static inline bool tn_wide_ok(int rows_per_split, int64_t ld0, int64_t ld1, int64_t ld2) {
+    const int64_t r = (int64_t)rows_per_split + 64, lim = (int64_t)1 << 31;
+    return r * ld0 * 4 < lim && r * ld1 * 4 < lim && r * ld2 * 4 < lim;
 }
 static void launch_tn_wide(const float* G, int64_t ldg, const float* G2, int64_t ldg2, const float* Z, int64_t ldz, float* part,
                            int64_t sstride, int64_t n_rows, int M, int K, const TnPlan& p, const float* ps, const float* psh,
@@ -1055,7 +1057,7 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
                        p.n_splits, pro_scale, pro_shift, (const float*)nullptr, (const float*)nullptr,           \
                        (const float*)nullptr, (const float*)nullptr, slope, gslot, zslot, target, heal_)
         const int mode_ = gemm_mode();
-        if (mode_ == 6 && gemm_f16() && tn_wide_ok(ldg, 0, ldz)) {
+        if (mode_ == 6 && gemm_f16() && tn_wide_ok(p.rows_per_split, ldg, 0, ldz)) {
             float* tail = (float*)((char*)workspace + need - 64);
             const bool own = !(ctx.a && ctx.b);
             gslot = own ? tail : ctx.a;
@@ -1227,7 +1229,7 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
                        (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale,       \
                        pro_shift, a, b, c1, c0, slope, gslot, zslot, target, heal_)
     const int mode_ = gemm_mode();
-    if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0 && tn_wide_ok(lddz, ldyb, ldz) &&
+    if (mode_ == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0 && tn_wide_ok(p.rows_per_split, lddz, ldyb, ldz) &&
         aligned16(dZ) && aligned16(Yb) && aligned16(Z)) {
         float* tail = (float*)((char*)workspace + need - 64);
         const bool own = !(ctx.a && ctx.b);

@@ -19,7 +19,8 @@
 //   * prologue, scale, split as before, but the two f16 planes are written ROW-major (ds_write_b64: one 512-byte row per wave
 //     instruction; 64-byte chunk c of row r at chunk c ^ (r & 3)) and the MFMA fragments -- 8 consecutive rows of one column --
 //     come out of ds_read_b64_tr_b16, the layout gemm_tn_b16_kernel (gemm_b16.hip) uses for bf16 features;
-//   * rows beyond the split are zeroed on the G side through the (scalar) scale, the BatchNorm coefficients sit in LDS.
+//   * rows beyond the split read as zeros through the descriptor of a plain operand (buffer range = the split), the BatchNorm
+//     coefficients sit in LDS.
 // The values that reach the MFMAs, their k order and the product order are those of the old kernel: same results bit for bit.
 #include "gemm_tn_rm.h"
 
@@ -118,20 +119,25 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     }
     __syncthreads();
 
-    // Operand rows through buffer loads: descriptor (SGPRs) = the operand from the split's first row, voffset = this lane's
-    // columns (one loop-invariant VGPR per operand), soffset = the wave's row (scalar, clamped to the matrix end) -- no 64-bit
-    // VGPR address is formed or rewritten while loads are in flight.
+    // Operand rows through buffer loads: descriptor (SGPRs) = the operand from the split's first row to its LAST row, voffset =
+    // this lane's column bytes + the wave's row bytes (one v_add per load: the row part is scalar).  The row goes through
+    // voffset, not soffset, because only voffset is range-checked: a load beyond the descriptor's range returns 0 without a
+    // fault, so rows past the split (and past the matrix) contribute nothing -- zero times anything finite is zero, the other
+    // operand needs no masking -- and no 64-bit VGPR address is formed or rewritten while loads are in flight.
+    // Only the G operand with the BatchNorm-backward prologue (it does not map 0 to 0) is zeroed by select (MASK), which also
+    // keeps its published maximum exact.
     const int voff_g = gcol * 4, voff_z = zcol * 4;              // byte offsets inside a row
     const unsigned ldg4 = (unsigned)(a.ldg * 4), ldg24 = (unsigned)(a.ldg2 * 4), ldz4 = (unsigned)(a.ldz * 4);
-    auto rsrc = [](const float* base, int64_t row, int64_t ld) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + row * ld), 0, 0x7fffffff, 0x00020000);
+    constexpr bool MASK = GDUAL;
+    auto rsrc = [&](const float* base, int64_t ld) {
+        const int64_t bytes = (int64_t)(r_end - r_begin) * ld * 4;                       // (< 2^31: launch_tn_rm checks)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (int64_t)r_begin * ld), 0, (int)bytes, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t Gd = rsrc(a.G, r_begin, a.ldg), Zd = rsrc(a.Z, r_begin, a.ldz);
-    const __amdgpu_buffer_rsrc_t G2d = rsrc(GDUAL ? a.G2 : a.G, r_begin, GDUAL ? a.ldg2 : a.ldg);
-    const int r_last = n_rows - 1 - r_begin;                     // last row of the matrix, relative to the split
+    const __amdgpu_buffer_rsrc_t Gd = rsrc(a.G, a.ldg), Zd = rsrc(a.Z, a.ldz);
+    const __amdgpu_buffer_rsrc_t G2d = rsrc(GDUAL ? a.G2 : a.G, GDUAL ? a.ldg2 : a.ldg);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    auto ldrow = [](__amdgpu_buffer_rsrc_t d, int voff, unsigned soff) __attribute__((always_inline)) -> float4 {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(d, voff, (int)soff, 0);
+    auto ldrow = [](__amdgpu_buffer_rsrc_t d, int voff, unsigned row_off) __attribute__((always_inline)) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(d, voff + (int)row_off, 0, 0);
         return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     };
 
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     auto load_z = [&](float4 (&z)[2], int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const unsigned rc = (unsigned)min(wave + stage * kRows + 8 * p, r_last);
+            const unsigned rc = (unsigned)(wave + stage * kRows + 8 * p);
             z[p] = ldrow(Zd, voff_z, rc * ldz4);
             DDMP_FENCE_();
         }
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
         if (ZL == 1) load_z(Z1, max(stage - 1, 0));
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const unsigned rc = (unsigned)min(wave + stage * kRows + 8 * p, r_last);        // scalar
+            const unsigned rc = (unsigned)(wave + stage * kRows + 8 * p);                   // scalar
             // (fences: the loads keep THIS order everywhere)
             sl.g[p] = ldrow(Gd, voff_g, rc * ldg4);
             DDMP_FENCE_();
@@ -206,8 +212,10 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
             } else {
                 x.x *= sg; x.y *= sg; x.z *= sg; x.w *= sg;
             }
-            const int row = r_begin + wave + stage * kRows + 8 * p;          // (scalar) rows beyond the split contribute nothing:
-            if (row >= r_end) x = make_float4(0.f, 0.f, 0.f, 0.f);            // a uniform branch, taken in a split's last stage only
+            if (MASK) {
+                const int row = r_begin + wave + stage * kRows + 8 * p;      // (scalar)
+                if (row >= r_end) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             gmax = amax4(gmax, x);
             const int o = rm_off(wave + 8 * p, c4);
             split_store(x, &Gs[buf][0][o], &Gs[buf][1][o]);

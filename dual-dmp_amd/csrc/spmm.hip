@@ -524,12 +524,12 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
         }
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
-    int red_chunks = n_chunks;
+    int red_groups = n_chunks * 4;                               // slab kernel: one record per wave and chunk
     const LeanPlan lp = lean_plan(g, ldx, ldy, C, 2);
     if (lp.kind) {
         const int rc = launch_lean<false, true, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
         if (rc != DDMP_OK) return rc;
-        red_chunks = lp.n_chunks;
+        red_groups = lp.n_chunks;                                // lean kernel: one record per chunk
     } else {
         hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
                            g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -537,7 +537,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
         LAUNCH_TRY();
     }
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, red_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    fpartials_reduce((const float*)ws, red_groups, C, C, (double*)((char*)ws + pbytes), sums2, st);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -568,7 +568,7 @@ extern "C" int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t 
                              : launch_lean<false, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)lp.n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, lp.n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
+    fpartials_reduce((const float*)ws, lp.n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -7,7 +7,7 @@ rm -f $O/summary.txt
 cd /tmp; export TMPDIR=/tmp
 for which in ${WHICH_LIST:-bnbwd plain}; do
   export TN_WHICH=$which
-  echo "=== $which  DDMP_TN_PP=${DDMP_TN_PP:-0} DDMP_TN_RM=${DDMP_TN_RM:-1}" >> $O/summary.txt
+  echo "=== $which  DDMP_TN_PP=${DDMP_TN_PP:-0}" >> $O/summary.txt
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
