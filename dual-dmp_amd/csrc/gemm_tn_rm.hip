@@ -423,13 +423,11 @@ void launch_tn_rm(const TnRmArgs& a, hipStream_t st) {
     // DDMP_TN_PP=0: the same segment order on all waves (A/B; measured 6-9 % slower: profiles/r04_tn_kernel_ab.txt)
     static const int pp = [] { const char* e = getenv("DDMP_TN_PP"); return e ? atoi(e) : 1; }();
 #define DDMP_L_(P_, G_, Q_) hipLaunchKernelGGL((gemm_tn_rm_kernel<P_, G_, Q_>), grid, block, 0, st, a)
-#define DDMP_LQ_(Q_)                                                                              \
-    do {                                                                                          \
-        if (gdual) { if (pro) DDMP_L_(true, true, Q_); else DDMP_L_(false, true, Q_); }           \
-        else { if (pro) DDMP_L_(true, false, Q_); else DDMP_L_(false, false, Q_); }               \
-    } while (0)
-    if (pp == 0) DDMP_LQ_(0); else DDMP_LQ_(1);
-#undef DDMP_LQ_
+    // (three operand streams: always the common order -- in the rotated loop hipcc puts a full vmcnt drain in front of the Z
+    //  conversion, and measured the two forms tie: profiles/r04_tn_kernel_ab.txt)
+    if (gdual) { if (pro) DDMP_L_(true, true, 0); else DDMP_L_(false, true, 0); }
+    else if (pp == 0) { if (pro) DDMP_L_(true, false, 0); else DDMP_L_(false, false, 0); }
+    else { if (pro) DDMP_L_(true, false, 1); else DDMP_L_(false, false, 1); }
 #undef DDMP_L_
 }
 

@@ -63,4 +63,4 @@ for st in starts:
             tag, name, len(ins), n_mfma, n_ld, waits, ("   <-- " + "; ".join(bad)) if bad else ""))
         problems += bool(bad)
 print("kernels audited: %d, problems: %d" % (n_kernels, problems))
-sys.exit(1 if problems or n_kernels != 8 else 0)
+sys.exit(1 if problems or n_kernels != 6 else 0)
