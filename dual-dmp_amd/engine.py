@@ -196,7 +196,9 @@ class GcnEngine:
         self.x_pos = None if x_pos is None else x_pos[:self.n_rows].contiguous().to(torch.float32)
         # aggregate on the narrower side; equal widths aggregate first too: then dY feeds only GEMMs and, where the
         # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
-        self.agg_first = [L.cin_p[l] <= L.cout[l] for l in range(12)]
+        # (DDMP_EQUAL_WIDTH=transform: equal widths transform first, the reference's own order -- A/B)
+        eq_agg = os.environ.get("DDMP_EQUAL_WIDTH", "agg") != "transform"
+        self.agg_first = [L.cin_p[l] < L.cout[l] or (eq_agg and L.cin_p[l] == L.cout[l]) for l in range(12)]
         supported = getattr(ops, "gemm_bnbwd_supported", None)
         def _bnbwd_ok(l):
             if not supported or l == 0 or not self.agg_first[l]:
@@ -235,12 +237,13 @@ class GcnEngine:
         self.bn4 = [torch.zeros((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         # transform-first layers, float32: BatchNorm statistics from the gather's epilogue (ddmp_spmm_stats_f32)
         st_ok = getattr(ops, "spmm_stats_supported", None)
-        # OPT-IN (DDMP_SPMM_STATS=1): measured -0.15 ... -0.3 ms per step at 1M faces (A/B on one box: 46.23 -> 46.07,
-        # 46.24 -> 45.93 ms), i.e. within the pool's box-to-box spread, while the epilogue's work lands in the gather family
-        # and takes ~0.03 off its achieved-bandwidth fraction (same algorithmic bytes, 0.7 ms more time) -- the north star's
-        # gather figure is kept clean.  bf16 features: a tie (26.87 / 26.93 vs 26.98 / 26.77 ms).
+        # On by default since round 4 (DDMP_SPMM_STATS=0 for A/B): -0.3 ... -0.4 ms per step at 1M faces, the same sign in every
+        # interleaved A/B (round 3: 46.23 -> 46.07, 46.24 -> 45.93; round 4, scripts/layer_order_ab.sh: 46.38 / 46.23 -> 45.95 /
+        # 45.93 ms).  The epilogue's work lands in the gather family (+0.6 ms there, -0.7 ms of bn_stats passes) and takes ~0.02
+        # off that family's achieved-bandwidth fraction at the same algorithmic bytes -- the step is what is timed.
+        # bf16 features: a tie (26.87 / 26.93 vs 26.98 / 26.77 ms), no fused form.
         self.fuse_spmm_stats = [bool(st_ok) and not self.agg_first[l] and st_ok(L.cout[l], dtype)
-                                and os.environ.get("DDMP_SPMM_STATS", "0") == "1" for l in range(12)]
+                                and os.environ.get("DDMP_SPMM_STATS", "1") != "0" for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
         # weights split into their 16-bit planes once per iteration, all layers in two launches (float32 features)

@@ -209,3 +209,33 @@ def test_wide_wgrad_isa_audit():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_tn_asm.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "kernels audited: 6, problems: 0" in r.stdout
+
+
+def test_bench_parity_object_bounds():
+    """bench.py's parity_1m object (HIP iteration 1 vs the oracle's, SURVEY.md 8d bounds): within the bounds -> ok; one face off
+    by 5e-3 on a small mesh -> not ok (the quantile clause only forgives <= 1e-5 of the faces); a loss off by 1e-4 -> not ok."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ddmp_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.mesh import Mesh
+    v, f = synth.torus(24, 12)
+    m = Mesh.__new__(Mesh)
+    m.vs, m.faces = np.asarray(v, dtype=np.float64), np.asarray(f)
+    Mesh.compute_face_normals(m)
+    g = torch.Generator().manual_seed(3)
+    pos = torch.tensor(m.vs, dtype=torch.float32)
+    norm = torch.tensor(m.fn, dtype=torch.float32)
+    hip = {"loss": [1.0, 0.9], "pos": pos, "norm": norm, "faces": len(f), "mesh_faces": m.faces, "gt_fn": m.fn}
+    ref = {"loss": [1.0 + 2e-6, 0.91], "pos": pos + 1e-6 * torch.randn(pos.shape, generator=g),
+           "norm": norm + 1e-6 * torch.randn(norm.shape, generator=g)}
+    out = bench.parity_object(hip, ref)
+    assert out["ok"] and out["rel"] < 1e-5 and out["dnorm_rows_above_1e-3"] == 0 and out["dnorm_p9999"] < 1e-4
+    bad = dict(ref, norm=ref["norm"].clone())
+    bad["norm"][7, 1] += 5e-3
+    out = bench.parity_object(hip, bad)
+    assert not out["ok"] and out["dnorm_rows_above_1e-3"] == 1 and out["max_abs_dnorm"] > 4e-3
+    out = bench.parity_object(hip, dict(ref, loss=[1.0 + 1e-4, 0.9]))
+    assert not out["ok"]
