@@ -239,3 +239,14 @@ def test_bench_parity_object_bounds():
     assert not out["ok"] and out["dnorm_rows_above_1e-3"] == 1 and out["max_abs_dnorm"] > 4e-3
     out = bench.parity_object(hip, dict(ref, loss=[1.0 + 1e-4, 0.9]))
     assert not out["ok"]
+    # with the float64 forward: both float32 paths are measured against it; a HIP path no further from the truth than twice the
+    # float32 reference passes the normals clause even when a few rows exceed the absolute bound
+    truth_p, truth_n = pos.double(), norm.double()
+    noisy_ref = dict(ref, pos64=truth_p, norm64=truth_n, f64_forward_s=1.0, norm=norm + 2e-3 * torch.randn(norm.shape, generator=g))
+    noisy_hip = dict(hip, norm=norm + 2e-3 * torch.randn(norm.shape, generator=g))
+    out = bench.parity_object(noisy_hip, noisy_ref)
+    v = out["vs_float64"]
+    assert out["max_abs_dnorm"] > 1e-3 and v["hip_within_2x_of_the_float32_reference"] and out["ok"]
+    assert abs(v["hip"]["dnorm_rms"] - v["oracle_float32"]["dnorm_rms"]) < 0.5 * v["oracle_float32"]["dnorm_rms"]
+    out = bench.parity_object(dict(hip, norm=norm + 2e-2 * torch.randn(norm.shape, generator=g)), noisy_ref)
+    assert not out["vs_float64"]["hip_within_2x_of_the_float32_reference"] and not out["ok"]
