@@ -532,6 +532,43 @@ def test_timed_configuration_is_bit_identical_to_eager_at_144k(dev, dtype):
     assert all(np.isfinite(a[0]))
 
 
+@pytest.mark.parametrize("env", [{"DDMP_SPMM_STATS": "0"}, {"DDMP_EQUAL_WIDTH": "transform"},
+                                 {"DDMP_EQUAL_WIDTH": "transform", "DDMP_SPMM_STATS": "0"}])
+def test_layer_order_and_statistics_switches_agree_with_the_default(dev, monkeypatch, env):
+    """Round 4: the forward statistics of the transform-first layers come from the gather's epilogue by default
+    (DDMP_SPMM_STATS=0: the separate pass), equal-width layers aggregate first (DDMP_EQUAL_WIDTH=transform: the reference's own
+    order).  Same mathematics, other summation orders / kernels: the first iteration from identical weights agrees to float32
+    rounding -- loss, outputs, and the gradients that iteration produced (seen through the Adam moments)."""
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    gt, noisy, smooth, data = _case(dev, "torus144k")
+    runs = []
+    for e in ({}, env):
+        for k in ("DDMP_SPMM_STATS", "DDMP_EQUAL_WIDTH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in e.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(5)
+        posnet, normnet = PosNet(dev), NormalNet(dev)
+        tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=1)
+        loss = tr.step().item()
+        torch.cuda.synchronize()
+        eng = tr.neng
+        if e.get("DDMP_SPMM_STATS") == "0":
+            assert not any(eng.fuse_spmm_stats)
+        elif not e:
+            assert sum(eng.fuse_spmm_stats) >= 3, "the default does not take the statistics epilogue"
+        if e.get("DDMP_EQUAL_WIDTH") == "transform":
+            assert not any(eng.agg_first[l] for l in range(12) if eng.layout.cin_p[l] == eng.layout.cout[l])
+        runs.append((loss, tr.pos.clone(), tr.norm.clone(), tr.m[0].clone(), tr.m[1].clone()))
+        del tr, posnet, normnet
+    a, b = runs
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]), (a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 and float((a[2] - b[2]).abs().max()) <= 2e-4
+    for x, y in ((a[3], b[3]), (a[4], b[4])):               # Adam's first moment = (1 - beta1) * gradient
+        assert float((x - y).norm() / (y.norm() + 1e-30)) <= 2e-4
+
+
 @pytest.mark.parametrize("which,dtype", [("grid", torch.float32), ("grid", torch.bfloat16), ("torus48k", torch.float32)])
 def test_launch_fusions_are_bit_identical(dev, monkeypatch, which, dtype):
     """Round 3: BatchNorm coefficients written by the second stage of the reduction that produced their sums
