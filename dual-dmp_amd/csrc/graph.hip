@@ -112,11 +112,11 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
         std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, tmp;
         std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1));
         int max_patch = 0;
-        // tables for the LDS-patch gather (spmm_patch.hip): by default for the graphs it is selected on -- at most 5 entries
-        // per row (the face graph), from 64k rows; DDMP_SPMM_PATCH=1 every graph (A/B), =0 none
+        // tables for the LDS-patch gather (spmm_patch.hip): by default for the graphs it is selected on -- at most 8 entries
+        // per row (face and vertex graphs of a mesh), from 64k rows; DDMP_SPMM_PATCH=1 every graph (A/B), =0 none
         const char* pe = getenv("DDMP_SPMM_PATCH");
         const int pm = pe ? atoi(pe) : 3;
-        bool ok = g->nnz > 0 && (pm == 1 || (pm != 0 && mx <= 5 && n_rows >= 65536));
+        bool ok = g->nnz > 0 && (pm == 1 || (pm != 0 && mx <= 8 && n_rows >= 65536));
         for (int64_t c = 0; c < n_chunks && ok; ++c) {
             const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
             tmp.assign(col + rowptr[r0], col + rowptr[r1]);

@@ -64,7 +64,11 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 // KD: copies per wave and slab of the patch (8 rows each, 4 waves): the patch buffer holds 32 KD rows
 // NB: patch buffers (2: 41-57 KB of LDS per workgroup, two to three workgroups per CU hide each other's copy latency and
 // barriers; 4: the round-2 form, one workgroup per CU pipelining three slabs ahead)
-template <typename T, int KD, bool PRO, bool RED, int NB>
+// NE: 0 = entries read from LDS per slab (any row length) | 4, 8 = every row of the graph has at most NE entries: a lane keeps
+// the patch offsets and weights of its two rows' entries in REGISTERS for all slabs of the chunk (round 4: the index and weight
+// reads were two of the three LDS instructions per gathered row; without them the 7-entry vertex graph went from 547 to 447 us
+// at C = 512 in a timing-only build), the gather of a slab is then NE ds_read_b128 with immediate buffer offsets per row
+template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
     const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
@@ -122,6 +126,32 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         s_w[t] = dinv[col[e0 + t]];
     }
     __syncthreads();                                             // (plain loads above: all waited for by now)
+
+    // NE > 0: this lane's rows (wave * 8 + grp, + 32) -- byte offset of the entry's patch row (+ the lane's 16 bytes) and weight;
+    // a row's missing entries repeat its last one with weight 0 (no further distinct LDS row, the sum unchanged)
+    constexpr int NEc = NE > 0 ? NE : 1;
+    int lo[2][NEc];
+    float wjr[2][NEc];
+    int nmax = 0;                                                // most entries of a row of this WAVE (uniform)
+    if (NE > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lr = wave * 8 + grp + 32 * q;
+            const int lrc = min(lr, nr - 1);
+            const int es = s_rowptr[lrc] - e0;
+            const int nn = lr < nr ? s_rowptr[lrc + 1] - s_rowptr[lrc] : 0;
+            nmax = max(nmax, nn);
+#pragma unroll
+            for (int k = 0; k < NEc; ++k) {
+                const int ek = es + min(k, max(nn, 1) - 1);
+                lo[q][k] = (int)s_lc[ek] * 128 + sl * 16;
+                wjr[q][k] = k < nn ? s_w[ek] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+    }
 
     const int n_slabs = C / CS;
     const T* xlane = X + sl * VW;
@@ -190,6 +220,27 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             float acc[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+            if (NE > 0) {                                        // entries from registers: the same sums in the same order
+                const unsigned char* pq = bufs + B * kBuf;       // (compile-time buffer: immediate offsets)
+#pragma unroll
+                for (int k0 = 0; k0 < NEc; k0 += 4) {
+                    if (k0 >= nmax) break;                       // (uniform)
+                    uint4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t[VW];
+                        Lane<T>::unpack(v[k], t);
+#pragma unroll
+                        for (int j = 0; j < VW; ++j) {
+                            const float x = PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
+                            acc[j] = fmaf(wjr[q][k0 + k], x, acc[j]);
+                        }
+                    }
+                }
+                es = ee;
+            }
             while (es < ee) {
                 int li[4];
                 float wj[4];
@@ -283,14 +334,14 @@ size_t patch2_lds(int C) {
     return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4;
 }
 
-template <typename T, int KD, bool PRO, bool RED, int NB>
+template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
 int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                     const float* psh, float slope, hipStream_t st, RedArgs red) {
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
-    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C);
-    auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB>;
+    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C);   // (the same for every NE)
+    auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB, NE>;
     static bool attr_done = false;                               // > 64 KB of dynamic LDS needs the attribute once per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -302,12 +353,20 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
     return DDMP_OK;
 }
 
+int patch_ne() {                                                  // DDMP_SPMM_PATCH_NE=0: entries from LDS per slab (A/B)
+    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_NE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <typename T, int KD, bool PRO, bool RED>
 int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                   const float* psh, float slope, hipStream_t st, RedArgs red) {
-    if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-    if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-    return launch_patch2nb<T, KD, PRO, RED, 2>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    // (the A/B buffer counts keep the LDS-entry form)
+    if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if (patch_ne() && g->max_row_nnz <= 4) return launch_patch2nb<T, KD, PRO, RED, 2, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if (patch_ne() && g->max_row_nnz <= 8) return launch_patch2nb<T, KD, PRO, RED, 2, 8>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    return launch_patch2nb<T, KD, PRO, RED, 2, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
 template <typename T, bool PRO, bool RED>
@@ -323,12 +382,19 @@ int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, in
     }
 }
 
-// Where this kernel runs (round 4: part of the default library).  Measured on MI355X, 1M-face mesh, float32, two patch buffers
-// (profiles/r03_experiments/spmm_patch_two_buffers.txt): on the FACE graph (4 entries per row) at C >= 256 it moves 5.1-5.2
-// TB/s -- 0.635-0.655 of 8 TB/s, the rate of a device copy -- against 0.575-0.59 for the lean gather (C = 256: 396 vs 450 us,
-// C = 512: 811 vs 840; with the BatchNorm+LeakyReLU prologue 406 vs 460 at C = 256 but 1071 vs 880 at C = 512); it loses at
-// C <= 128, with a fused reduction and on the 7-entry vertex graph.  DDMP_SPMM_PATCH: unset = that selection (float32, <= 5
-// entries per row, plain C >= 256 | prologue 256 <= C < 512), 0 = never, 1 = wherever it applies (A/B runs).
+// Where this kernel runs (round 4: part of the default library).  Measured on MI355X, 1M-face mesh in Morton order, float32, two
+// patch buffers, entries in registers (NE; profiles/r04_gather_patch_ab.txt), us per launch against the lean gather:
+//   face graph (4 entries per row)    plain C = 512 797 vs 866, C = 256 408 vs 435; prologue C = 256 412 vs 446, C = 512 930 vs 900;
+//                                     with the fused reduction 1342 vs 1271 / 664 vs 646; C = 128 227 vs 209
+//   vertex graph (7 entries per row)  plain C = 512 468 vs 558, C = 256 251 vs 272; prologue C = 256 264 vs 289, C = 512 581 vs 597;
+//                                     with the fused reduction 897 vs 755 / 367 vs 384; C = 128 152 vs 132
+// (before the entries moved to registers the vertex graph lost everywhere: 583 / 277 us plain).  DDMP_SPMM_PATCH: unset = the
+// selection that follows from this (float32, rows of <= 8 entries, plain C >= 256 | prologue 256 <= C < 512), 0 = never,
+// 1 = wherever it applies (A/B runs).
+int patch_max_nnz() {                                             // DDMP_SPMM_PATCH_MAXNNZ=5: the face graph only (A/B)
+    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_MAXNNZ"); return (e && atoi(e) > 0) ? atoi(e) : 8; }();
+    return v;
+}
 int patch_mode() {
     static int m = -1;
     if (m < 0) {
@@ -344,7 +410,9 @@ int patch_mode() {
 // does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
 extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red) {
     if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || g->max_row_nnz > kMaxE / kRB || !g->lcol) return 0;
-    if (patch_mode() == 3 && (dtype != DDMP_F32 || has_red || g->max_row_nnz > 5 || C < 256 || (has_pro && C >= 512))) return 0;
+    // (measured selection, see by_patch's note: float32, no fused reduction, rows of at most 8 entries -- the register-entry form --,
+    //  plain C >= 256, prologue 256 <= C < 512)
+    if (patch_mode() == 3 && (dtype != DDMP_F32 || has_red || g->max_row_nnz > patch_max_nnz() || C < 256 || (has_pro && C >= 512))) return 0;
     const int cs = dtype == DDMP_BF16 ? 64 : 32;
     return (C % cs == 0 && C >= 2 * cs && C <= 1024) ? 1 : 0;
 }

@@ -78,7 +78,7 @@ int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t
 int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
                   const float* bias, const float* pro_scale, const float* pro_shift, float slope,
                   ddmp_stream stream);
-/* 1: ddmp_spmm* runs its LDS-patch form for this graph and shape (float32 features, <= 5 entries per row, C >= 256, from 64k
+/* 1: ddmp_spmm* runs its LDS-patch form for this graph and shape (float32 features, <= 8 entries per row, C >= 256, from 64k
  * rows: distinct rows of a 64-row chunk copied to LDS once, gathers from LDS -- csrc/spmm_patch.hip); same results either way */
 int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red);
 

@@ -84,9 +84,11 @@ def test_spmm_matches_dense(dev, graphs, C, gname):
 
 def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
     """Round 4: the LDS-patch gather (csrc/spmm_patch.hip: distinct rows of a 64-row chunk copied to LDS once by DMA, gathers
-    from LDS) is part of the default library and selected for float32 features on graphs with <= 5 entries per row from 64k
-    rows at C >= 256 (plain) / C = 256 (prologue).  144,400-face torus: the route is asserted, results against a float64
-    sparse product; the 7-entry vertex graph and the narrow widths stay on the lean gather."""
+    from LDS, the entries' patch offsets and weights in registers) is part of the default library and selected for float32
+    features on graphs with <= 8 entries per row from 64k rows at C >= 256 (plain) / C = 256 (prologue).  144,400-face torus,
+    FACE graph (4 entries per row: NE = 4) and VERTEX graph (7 entries: NE = 8): the route is asserted, results against a
+    float64 sparse product and -- same sums in the same order -- bit for bit against the lean gather's; fused reductions and
+    the narrow widths stay on the lean gather."""
     from dual_dmp_amd import ops, synth, _lib
     from dual_dmp_amd.mesh import Mesh
     if os.environ.get("DDMP_SPMM_PATCH") == "0":
@@ -94,31 +96,36 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
     v, f = synth.morton_relabel(*synth.torus(380, 190))          # (the engines relabel along a Morton curve: compact patches)
     m = Mesh(vs=v, faces=f)
     fi = torch.from_numpy(m.f_edges)
-    n = len(f)
-    g = ops.graph_for(fi.to(dev), n)
+    e = torch.tensor(m.edges.T, dtype=torch.long)
+    vi = torch.cat([e, e[[1, 0]]], 1)
     L = _lib.lib()
-    assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1
-    assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
-    if os.environ.get("DDMP_SPMM_PATCH") is None:
-        assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
-        assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 0
-        e = torch.tensor(m.edges.T, dtype=torch.long)
-        gv = ops.graph_for(torch.cat([e, e[[1, 0]]], 1).to(dev), len(v))
-        assert L.ddmp_spmm_patch_selected(gv._h, 256, 0, 0, 0) == 0
-    # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
-    src = torch.cat([fi[0], torch.arange(n)])
-    dst = torch.cat([fi[1], torch.arange(n)])
-    deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(len(dst), dtype=torch.float64))
-    w = deg[src].pow(-0.5) * deg[dst].pow(-0.5)
-    A = torch.sparse_coo_tensor(torch.stack([dst, src]), w, (n, n)).coalesce()
-    for C in (256, 512):
-        torch.manual_seed(C)
-        x = torch.randn(n, C)
-        y = ops.spmm(g, x.to(dev))
-        assert relerr(y, torch.sparse.mm(A, x.double())) < 1e-6
-        a, b, bias = torch.rand(C) + 0.5, torch.randn(C), torch.randn(C)
-        y = ops.spmm(g, x.to(dev), bias=bias.to(dev), pro=(a.to(dev), b.to(dev)))
-        assert relerr(y, torch.sparse.mm(A, f_ref(x.double(), a.double(), b.double())) + bias.double()) < 1e-6
+    for ei, n in ((fi, len(f)), (vi, len(v))):
+        g = ops.graph_for(ei.to(dev), n)
+        sel = L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1       # (144,400 faces / 72,200 vertices: both from 64k rows)
+        assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
+        if os.environ.get("DDMP_SPMM_PATCH") is None:
+            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 0
+        # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
+        src = torch.cat([ei[0], torch.arange(n)])
+        dst = torch.cat([ei[1], torch.arange(n)])
+        deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(len(dst), dtype=torch.float64))
+        w = deg[src].pow(-0.5) * deg[dst].pow(-0.5)
+        A = torch.sparse_coo_tensor(torch.stack([dst, src]), w, (n, n)).coalesce()
+        for C in (256, 512):
+            torch.manual_seed(C)
+            x = torch.randn(n, C)
+            a, b, bias = torch.rand(C) + 0.5, torch.randn(C), torch.randn(C)
+            y = ops.spmm(g, x.to(dev))
+            yp = ops.spmm(g, x.to(dev), bias=bias.to(dev), pro=(a.to(dev), b.to(dev)))
+            assert relerr(y, torch.sparse.mm(A, x.double())) < 1e-6
+            assert relerr(yp, torch.sparse.mm(A, f_ref(x.double(), a.double(), b.double())) + bias.double()) < 1e-6
+            # the fused-reduction form runs the lean gather: its output is the same sums in the same order
+            if sel:
+                out = torch.empty_like(y)
+                bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5]).to(dev)
+                ops.spmm_bnred(g, x.to(dev), out, torch.randn(n, C, device=dev), bn4, torch.zeros(2 * C, dtype=torch.float64, device=dev))
+                assert torch.equal(out, y)
 
 
 @pytest.mark.parametrize("C", [32, 256, 8])
