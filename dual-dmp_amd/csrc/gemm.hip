@@ -330,19 +330,28 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 }
 
 struct TnPlan {
-    int T, n_tiles_m, n_tiles_k, n_splits, rows_per_split;      // T = 4: 256 x 256 panels (gemm_tn_panel_kernel)
+    int T, n_tiles_m, n_tiles_k, n_splits, rows_per_split;      // T = 4: 512-thread panels of tm x tk (256 x 256; f16x3 route
+    int tm, tk;                                                  // of round 4 also 256 x 128 | 128 x 256: gemm_tn_rm.hip)
 };
 
 bool tn_panel_enabled();
 int64_t tn_panel_min_rows();
 
-TnPlan tn_plan(int64_t n_rows, int M, int K) {
+// narrow_panels: the caller takes the f16x3 route of gemm_tn_rm.hip, which also has 256 x 128 and 128 x 256 panels (the
+// 128 <-> 256 layers; DDMP_TN_NARROW_PANELS=0: those stay on the tiled bf16x6 kernel, A/B)
+TnPlan tn_plan(int64_t n_rows, int M, int K, bool narrow_panels = false) {
     TnPlan p;
     p.T = (M >= 128 && K >= 128) ? 2 : 1;
-    if (M >= 256 && K >= 256 && n_rows >= tn_panel_min_rows() && tn_panel_enabled()) {
+    p.tm = p.tk = 0;
+    static const bool narrow_on = [] { const char* e = getenv("DDMP_TN_NARROW_PANELS"); return !(e && atoi(e) == 0); }();
+    const bool wide = M >= 256 && K >= 256;
+    const bool narrow = narrow_panels && narrow_on && ((M >= 256 && K == 128) || (M == 128 && K >= 256));
+    if ((wide || narrow) && n_rows >= tn_panel_min_rows() && tn_panel_enabled()) {
         p.T = 4;
-        p.n_tiles_m = (int)cdiv(M, 256);
-        p.n_tiles_k = (int)cdiv(K, 256);
+        p.tm = M >= 256 ? 256 : 128;
+        p.tk = K >= 256 ? 256 : 128;
+        p.n_tiles_m = (int)cdiv(M, p.tm);
+        p.n_tiles_k = (int)cdiv(K, p.tk);
         const int tiles = p.n_tiles_m * p.n_tiles_k;
         // one 512-thread workgroup per CU; at least 256 rows (16 stages) per split; multiple of 8 splits (XCD mapping)
         int64_t s = std::min<int64_t>(std::max<int64_t>(1, kCu / tiles), std::max<int64_t>(1, n_rows / 256));
@@ -1020,13 +1029,14 @@ static void launch_tn_wide(const float* G, int64_t ldg, const float* G2, int64_t
     a.n_rows = (int)n_rows; a.M = M; a.K = K; a.rows_per_split = p.rows_per_split; a.n_tiles_m = p.n_tiles_m;
     a.n_tiles_k = p.n_tiles_k; a.n_splits = p.n_splits; a.pscale = ps; a.pshift = psh; a.ga = ga; a.gb = gb; a.gk1 = gk1;
     a.gk0 = gk0; a.slope = slope; a.gslot = gslot; a.zslot = zslot; a.target = target; a.heal = heal;
+    a.tm = p.tm; a.tk = p.tk;
     ddmp::launch_tn_rm(a, st);
 }
 
 extern "C" size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K) {
     if (n_rows <= 0 || M <= 0 || K <= 0) return 0;
-    TnPlan p = tn_plan(n_rows, M, K);
-    return (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;    // + two scale slots (f16 modes)
+    const TnPlan p = tn_plan(n_rows, M, K), q = tn_plan(n_rows, M, K, true);    // (whichever route the call takes)
+    return (size_t)std::max(p.n_splits, q.n_splits) * (size_t)M * (size_t)K * sizeof(float) + 64;    // + two scale slots (f16 modes)
 }
 
 extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW,
@@ -1040,7 +1050,9 @@ extern "C" int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
     ARG_TRY(!pro_scale || (aligned16(pro_scale) && aligned16(pro_shift)));
     hipStream_t st = (hipStream_t)stream;
-    TnPlan p = tn_plan(n_rows, M, K);
+    const bool f16_route = gemm_mode() == 6 && gemm_f16();
+    TnPlan p = tn_plan(n_rows, M, K, f16_route);
+    if (p.T == 4 && p.tm + p.tk < 512 && !tn_wide_ok(p.rows_per_split, ldg, 0, ldz)) p = tn_plan(n_rows, M, K);
     const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;
     if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
     float* part = (float*)workspace;
@@ -1192,7 +1204,10 @@ extern "C" int ddmp_gemm_tn_bnbwd_f32(const float* dZ, int64_t lddz, const float
     ARG_TRY((pro_scale == nullptr) == (pro_shift == nullptr));
     if (!ddmp_gemm_tn_bnbwd_supported(M, K, n_rows)) return DDMP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    TnPlan p = tn_plan(n_rows, M, K);
+    const bool f16_route = gemm_mode() == 6 && gemm_f16() && lddz % 4 == 0 && ldyb % 4 == 0 && ldz % 4 == 0 && aligned16(dZ) &&
+                           aligned16(Yb) && aligned16(Z);
+    TnPlan p = tn_plan(n_rows, M, K, f16_route);
+    if (p.T == 4 && p.tm + p.tk < 512 && !tn_wide_ok(p.rows_per_split, lddz, ldyb, ldz)) p = tn_plan(n_rows, M, K);
     const size_t need = (size_t)p.n_splits * (size_t)M * (size_t)K * sizeof(float) + 64;
     if (!workspace || workspace_bytes < need) return DDMP_EWORKSPACE;
     float* part = (float*)workspace;

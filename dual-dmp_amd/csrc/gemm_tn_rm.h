@@ -21,9 +21,10 @@ struct TnRmArgs {
     float* gslot;                    // scale slots of the two operands (gemm_f16s.inc)
     float* zslot;
     int target, heal;
+    int tm, tk;                      // panel of dW per workgroup: 256 x 256 | 256 x 128 | 128 x 256 (n_tiles_* count these)
 };
 
-// grid = cdiv(n_splits, 8) * 8 * n_tiles_m * n_tiles_k workgroups of 512 threads (TnPlan of gemm.hip, T = 4)
+// grid = cdiv(n_splits, 8) * 8 * n_tiles_m * n_tiles_k workgroups of 512 threads (TnPlan of gemm.hip, T >= 4)
 void launch_tn_rm(const TnRmArgs& a, hipStream_t st);
 
 }  // namespace ddmp

@@ -40,10 +40,10 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kRows = 16;                                        // rows per stage = one MFMA k-step
 constexpr int kT = 256;                                          // panel edge
-constexpr int kPlane = kRows * kT;                               // f16 elements of one plane of one operand stage (8 KB)
 
-__device__ __forceinline__ int rm_off(int row, int col) {         // element offset in a [16][256] plane
-    return row * kT + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31));
+template <int T>
+__device__ __forceinline__ int rm_off(int row, int col) {         // element offset in a [16][T] plane (T = 256 | 128)
+    return row * T + ((((col >> 5) ^ (row & 3)) << 5) | (col & 31));
 }
 
 __device__ __forceinline__ void lds_barrier() {                  // LDS traffic only; register loads stay in flight
@@ -60,10 +60,13 @@ __device__ __forceinline__ void lds_barrier() {                  // LDS traffic 
 #define DDMP_FENCE_() __builtin_amdgcn_sched_barrier(0)
 
 // PP = 1: the two waves of a SIMD run the segments of an iteration in opposite order (see run_dm / run_md)
-template <bool PRO, bool GDUAL, int PP>
+// TM x TK: the panel of dW a workgroup owns -- 256 x 256, or (the 128 <-> 256 layers) 256 x 128 / 128 x 256: the 8 waves then
+// own 64 x 64 each, a 128-wide operand is staged as ONE load per thread and stage (a wave = two rows of 32 lanes)
+template <bool PRO, bool GDUAL, int PP, int TM = 256, int TK = 256>
 __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 Gs[2][2][kPlane];          // [buffer][term]
-    __shared__ __attribute__((aligned(16))) _Float16 Zs[2][2][kPlane];
+    static_assert((TM == 256 || TM == 128) && (TK == 256 || TK == 128) && TM + TK >= 384, "panel shapes");
+    __shared__ __attribute__((aligned(16))) _Float16 Gs[2][2][kRows * TM];      // [buffer][term]
+    __shared__ __attribute__((aligned(16))) _Float16 Zs[2][2][kRows * TK];
     __shared__ __attribute__((aligned(16))) float s_co[(GDUAL ? 4 : 0) + (PRO ? 2 : 0) + 1][kT];
 
     const int n_tiles = a.n_tiles_m * a.n_tiles_k;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     const int tile = local % n_tiles;
     const int split = (local / n_tiles) * kXcd + xcd;
     if (split >= a.n_splits) return;
-    const int tm0 = (tile / a.n_tiles_k) * kT, tk0 = (tile % a.n_tiles_k) * kT;
+    const int tm0 = (tile / a.n_tiles_k) * TM, tk0 = (tile % a.n_tiles_k) * TK;
     const int n_rows = a.n_rows, M = a.M, K = a.K;
     const int r_begin = split * a.rows_per_split;
     const int r_end = min(n_rows, r_begin + a.rows_per_split);
@@ -79,7 +82,8 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;                     // 4 x 2 waves: 64 (m) x 128 (k) each
+    constexpr int WK = TM == 256 ? 2 : 4, WTK = TK / WK, NJ = WTK / 32;      // waves: (8 / WK) x WK of 64 (m) x WTK (k)
+    const int wr = wave / WK, wc = wave % WK;
     const int l31 = lane & 31, lh = lane >> 5;
 
     float sg = 1.f, sz = 1.f, gmax = 0.f, zmax = 0.f;
@@ -95,25 +99,30 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
         sg = f16s_scale(g_use, target);
         sz = f16s_scale(z_use, target);
     }
-    // staging role: lane = 4 columns, wave = stage rows (wave, wave + 8).  Columns beyond M / K are clamped to valid ones
-    // (duplicates that only reach entries never stored).
+    // staging role.  256-wide operand: lane = 4 columns, wave = stage rows (wave, wave + 8): two loads.  128-wide operand: a wave
+    // = stage rows (2 wave, 2 wave + 1) of 32 lanes each: one load.  Columns beyond M / K are clamped to valid ones (duplicates
+    // that only reach entries never stored).
+    constexpr int GP = TM / 128, ZP = TK / 128;                  // loads per thread and stage
     const int c4 = lane * 4;
+    const int gc4 = TM == 256 ? c4 : (lane & 31) * 4, zc4 = TK == 256 ? c4 : (lane & 31) * 4;
     const float sgs = sg * slope;
-    const int gcol = min(tm0 + c4, M - 4), zcol = min(tk0 + c4, K - 4);
+    const int gcol = min(tm0 + gc4, M - 4), zcol = min(tk0 + zc4, K - 4);
     // Coefficient tables in LDS (read per stage: as loop invariants in registers they spill).  The operand scales (powers of
     // two: exact) are folded in -- G: a, b as they are (the gate multiplies by sg or sg * slope), k1 sg, k0 sg; Z: pscale sz, pshift sz (LeakyReLU
     // is positively homogeneous) -- so the conversion needs no separate multiply.
     constexpr int kCoZ = GDUAL ? 4 : 0;
-    if (GDUAL && tid < 64) {
-        const float4 ca = *reinterpret_cast<const float4*>(a.ga + gcol), k1 = *reinterpret_cast<const float4*>(a.gk1 + gcol);
-        const float4 k0 = *reinterpret_cast<const float4*>(a.gk0 + gcol);
+    if (GDUAL && tid < TM / 4) {                                 // (tid = lane here: c4 = the thread's columns of the table)
+        const int tcol = min(tm0 + c4, M - 4);
+        const float4 ca = *reinterpret_cast<const float4*>(a.ga + tcol), k1 = *reinterpret_cast<const float4*>(a.gk1 + tcol);
+        const float4 k0 = *reinterpret_cast<const float4*>(a.gk0 + tcol);
         *reinterpret_cast<float4*>(&s_co[0][c4]) = ca;
-        *reinterpret_cast<float4*>(&s_co[1][c4]) = *reinterpret_cast<const float4*>(a.gb + gcol);
+        *reinterpret_cast<float4*>(&s_co[1][c4]) = *reinterpret_cast<const float4*>(a.gb + tcol);
         *reinterpret_cast<float4*>(&s_co[GDUAL ? 2 : 0][c4]) = make_float4(k1.x * sg, k1.y * sg, k1.z * sg, k1.w * sg);
         *reinterpret_cast<float4*>(&s_co[GDUAL ? 3 : 0][c4]) = make_float4(k0.x * sg, k0.y * sg, k0.z * sg, k0.w * sg);
     }
-    if (PRO && tid >= 64 && tid < 128) {
-        const float4 sc = *reinterpret_cast<const float4*>(a.pscale + zcol), sh = *reinterpret_cast<const float4*>(a.pshift + zcol);
+    if (PRO && tid >= 64 && tid < 64 + TK / 4) {
+        const int tcol = min(tk0 + c4, K - 4);
+        const float4 sc = *reinterpret_cast<const float4*>(a.pscale + tcol), sh = *reinterpret_cast<const float4*>(a.pshift + tcol);
         *reinterpret_cast<float4*>(&s_co[kCoZ][c4]) = make_float4(sc.x * sz, sc.y * sz, sc.z * sz, sc.w * sz);
         *reinterpret_cast<float4*>(&s_co[kCoZ + (PRO ? 1 : 0)][c4]) = make_float4(sh.x * sz, sh.y * sz, sh.z * sz, sh.w * sz);
     }
@@ -126,8 +135,14 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     // operand needs no masking -- and no 64-bit VGPR address is formed or rewritten while loads are in flight.
     // Only the G operand with the BatchNorm-backward prologue (it does not map 0 to 0) is zeroed by select (MASK), which also
     // keeps its published maximum exact.
-    const int voff_g = gcol * 4, voff_z = zcol * 4;              // byte offsets inside a row
     const unsigned ldg4 = (unsigned)(a.ldg * 4), ldg24 = (unsigned)(a.ldg2 * 4), ldz4 = (unsigned)(a.ldz * 4);
+    // byte offsets of the lane inside the stage: its columns (+ its row of the wave's two for a 128-wide operand)
+    const int voff_g = gcol * 4 + (TM == 128 ? (int)((lane >> 5) * ldg4) : 0), voff_g2 = gcol * 4 + (TM == 128 ? (int)((lane >> 5) * ldg24) : 0);
+    const int voff_z = zcol * 4 + (TK == 128 ? (int)((lane >> 5) * ldz4) : 0);
+    // (scalar part of the stage row of load p) and the lane's row inside the stage
+    auto grow_s = [&](int p) __attribute__((always_inline)) { return TM == 256 ? wave + 8 * p : 2 * wave; };
+    auto zrow_s = [&](int p) __attribute__((always_inline)) { return TK == 256 ? wave + 8 * p : 2 * wave; };
+    const int grow_l = TM == 256 ? 0 : (lane >> 5), zrow_l = TK == 256 ? 0 : (lane >> 5);
     constexpr bool MASK = GDUAL;
     auto rsrc = [&](const float* base, int64_t ld) {
         const int64_t bytes = (int64_t)(r_end - r_begin) * ld * 4;                       // (< 2^31: launch_tn_rm checks)
@@ -146,14 +161,14 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     // in the rotated loop and copies slot registers whose loads are in flight, behind a vmcnt(0)).
     constexpr int ZL = GDUAL ? 1 : 2;
     struct Slot {
-        float4 g[2], z[ZL == 2 ? 2 : 1], g2[GDUAL ? 2 : 1];
+        float4 g[GP], z[ZL == 2 ? ZP : 1], g2[GDUAL ? GP : 1];
     };
     Slot S[2];
-    float4 Z1[2];                                                // ZL = 1: the one Z slot
-    auto load_z = [&](float4 (&z)[2], int stage) __attribute__((always_inline)) {
+    float4 Z1[ZP];                                               // ZL = 1: the one Z slot
+    auto load_z = [&](float4 (&z)[ZP], int stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned rc = (unsigned)(wave + stage * kRows + 8 * p);
+        for (int p = 0; p < ZP; ++p) {
+            const unsigned rc = (unsigned)(zrow_s(p) + stage * kRows);
             z[p] = ldrow(Zd, voff_z, rc * ldz4);
             DDMP_FENCE_();
         }
@@ -162,18 +177,21 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
         // (ZL = 1: Z of stage - 1, FIRST -- it is needed one iteration from now, before this call's G rows: the in-order
         //  counter then lets those stay in flight)
         if (ZL == 1) load_z(Z1, max(stage - 1, 0));
+        // (fences: the loads keep THIS order everywhere -- g [g2] z of load 0, then of load 1)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const unsigned rc = (unsigned)(wave + stage * kRows + 8 * p);                   // scalar
-            // (fences: the loads keep THIS order everywhere)
-            sl.g[p] = ldrow(Gd, voff_g, rc * ldg4);
-            DDMP_FENCE_();
-            if (GDUAL) {
-                sl.g2[GDUAL ? p : 0] = ldrow(G2d, voff_g, rc * ldg24);
+            if (p < GP) {
+                const unsigned rc = (unsigned)(grow_s(p) + stage * kRows);                  // scalar
+                sl.g[p < GP ? p : 0] = ldrow(Gd, voff_g, rc * ldg4);
                 DDMP_FENCE_();
+                if (GDUAL) {
+                    sl.g2[GDUAL && p < GP ? p : 0] = ldrow(G2d, voff_g2, rc * ldg24);
+                    DDMP_FENCE_();
+                }
             }
-            if (ZL == 2) {
-                sl.z[ZL == 2 ? p : 0] = ldrow(Zd, voff_z, rc * ldz4);
+            if (ZL == 2 && p < ZP) {
+                const unsigned rc = (unsigned)(zrow_s(p) + stage * kRows);
+                sl.z[ZL == 2 && p < ZP ? p : 0] = ldrow(Zd, voff_z, rc * ldz4);
                 DDMP_FENCE_();
             }
         }
@@ -192,11 +210,11 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     // (maxima of the SCALED operands; f16s_publish gets them un-scaled -- exactly, the scales are powers of two)
     auto amax4 = [](float m, float4 v) { return fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w)))); };
     auto store_g = [&](int buf, const Slot& sl, int stage) __attribute__((always_inline)) {
-        int co = c4;
+        int co = gc4;
         asm volatile("" : "+v"(co));                             // (keeps the coefficient reads inside the loop)
         __builtin_assume((co & 3) == 0);                         // (... as 16-byte reads: ds_read2_b32 pairs conflict 4-way)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < GP; ++p) {
             float4 x = sl.g[p];
             if (GDUAL) {                                         // = sg * BwdApplyF (bn.hip), element for element
                 const float4 y = sl.g2[GDUAL ? p : 0];
@@ -213,21 +231,21 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
                 x.x *= sg; x.y *= sg; x.z *= sg; x.w *= sg;
             }
             if (MASK) {
-                const int row = r_begin + wave + stage * kRows + 8 * p;      // (scalar)
+                const int row = r_begin + stage * kRows + grow_s(p) + grow_l;      // (scalar for a 256-wide operand)
                 if (row >= r_end) x = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             gmax = amax4(gmax, x);
-            const int o = rm_off(wave + 8 * p, c4);
+            const int o = rm_off<TM>(grow_s(p) + grow_l, gc4);
             split_store(x, &Gs[buf][0][o], &Gs[buf][1][o]);
         }
     };
     auto store_z = [&](int buf, const Slot& sl) __attribute__((always_inline)) {
         const float4* zsrc = ZL == 2 ? sl.z : Z1;
-        int co = c4;
+        int co = zc4;
         asm volatile("" : "+v"(co));
         __builtin_assume((co & 3) == 0);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < ZP; ++p) {
             float4 x = zsrc[p];
             if (PRO) {
                 const float4 sc = *reinterpret_cast<const float4*>(&s_co[kCoZ][co]);
@@ -237,28 +255,29 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
                 x.x *= sz; x.y *= sz; x.z *= sz; x.w *= sz;
             }
             zmax = amax4(zmax, x);
-            const int o = rm_off(wave + 8 * p, c4);
+            const int o = rm_off<TK>(zrow_s(p) + zrow_l, zc4);
             split_store(x, &Zs[buf][0][o], &Zs[buf][1][o]);
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // transpose reads: lane L = lane & 15 of a 16-lane group supplies the address of 4 consecutive columns of row (L >> 2)
     // and receives column (lane & 31) of the tile, rows 0..3 of the 4-row block (gemm_b16.hip)
     const int L = lane & 15, gi = (lane >> 4) & 1;
-    auto frag = [&](const _Float16* plane, int cbase) __attribute__((always_inline)) -> f16x8 {
+    auto frag = [&](const _Float16* plane, int cbase, auto tw) __attribute__((always_inline)) -> f16x8 {
+        constexpr int T = decltype(tw)::value;
         typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
         typedef __attribute__((address_space(3))) hf4* lp;
         const int r_lo = lh * 8 + (L >> 2), r_hi = r_lo + 4;
         const int col = cbase + 16 * gi + 4 * (L & 3);
-        const f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(plane + rm_off(r_lo, col))));
-        const f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(plane + rm_off(r_hi, col))));
+        const f16x4 lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(plane + rm_off<T>(r_lo, col))));
+        const f16x4 hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(plane + rm_off<T>(r_hi, col))));
         f16x8 o;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
         o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
@@ -271,21 +290,23 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     // none to spare (with them hipcc copies slot registers whose loads are in flight -- behind a vmcnt(0)).
     constexpr int NBF = GDUAL ? 1 : 2;
     auto seg_m = [&](int buf) __attribute__((always_inline)) {
+        constexpr std::integral_constant<int, TM> twm{};
+        constexpr std::integral_constant<int, TK> twk{};
         f16x8 af[2][2], bf[NBF][2];                              // [tile][term]
         if (NBF == 2) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) DDMP_TA_(8, bf[0][t] = frag(Zs[buf][t], wc * 128));
+            for (int t = 0; t < 2; ++t) DDMP_TA_(8, bf[0][t] = frag(Zs[buf][t], wc * WTK, twk));
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) DDMP_TA_(8, af[i][t] = frag(Gs[buf][t], wr * 64 + i * 32));
+            for (int i = 0; i < 2; ++i) DDMP_TA_(8, af[i][t] = frag(Gs[buf][t], wr * 64 + i * 32, twm));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (NBF == 1 || j < 3) {
+        for (int j = 0; j < NJ; ++j) {
+            if (NBF == 1 || j < NJ - 1) {
                 const int jn = NBF == 1 ? j : j + 1;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) DDMP_TA_(8, bf[jn % NBF][t] = frag(Zs[buf][t], wc * 128 + jn * 32));
+                for (int t = 0; t < 2; ++t) DDMP_TA_(8, bf[jn % NBF][t] = frag(Zs[buf][t], wc * WTK + jn * 32, twk));
             }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -364,9 +385,9 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     auto settle = [](const Slot& sl) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            asm volatile("" ::"v"(sl.g[p].x), "v"(sl.g[p].y), "v"(sl.g[p].z), "v"(sl.g[p].w));
-            if (ZL == 2) asm volatile("" ::"v"(sl.z[ZL == 2 ? p : 0].x), "v"(sl.z[ZL == 2 ? p : 0].y), "v"(sl.z[ZL == 2 ? p : 0].z), "v"(sl.z[ZL == 2 ? p : 0].w));
-            if (GDUAL) asm volatile("" ::"v"(sl.g2[GDUAL ? p : 0].x), "v"(sl.g2[GDUAL ? p : 0].y), "v"(sl.g2[GDUAL ? p : 0].z), "v"(sl.g2[GDUAL ? p : 0].w));
+            if (p < GP) asm volatile("" ::"v"(sl.g[p < GP ? p : 0].x), "v"(sl.g[p < GP ? p : 0].y), "v"(sl.g[p < GP ? p : 0].z), "v"(sl.g[p < GP ? p : 0].w));
+            if (ZL == 2 && p < ZP) asm volatile("" ::"v"(sl.z[ZL == 2 && p < ZP ? p : 0].x), "v"(sl.z[ZL == 2 && p < ZP ? p : 0].y), "v"(sl.z[ZL == 2 && p < ZP ? p : 0].z), "v"(sl.z[ZL == 2 && p < ZP ? p : 0].w));
+            if (GDUAL && p < GP) asm volatile("" ::"v"(sl.g2[GDUAL && p < GP ? p : 0].x), "v"(sl.g2[GDUAL && p < GP ? p : 0].y), "v"(sl.g2[GDUAL && p < GP ? p : 0].z), "v"(sl.g2[GDUAL && p < GP ? p : 0].w));
         }
     };
     if (ns > 0) {
@@ -395,8 +416,8 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     float* o = a.part + (int64_t)split * a.split_stride;
     const float out_scale = (1.f / sg) * (1.f / sz);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = tk0 + wc * 128 + j * 32 + l31;
+    for (int j = 0; j < NJ; ++j) {
+        const int k = tk0 + wc * WTK + j * 32 + l31;
         if (k >= K) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -422,12 +443,19 @@ void launch_tn_rm(const TnRmArgs& a, hipStream_t st) {
     const bool pro = a.pscale != nullptr, gdual = a.G2 != nullptr;
     // DDMP_TN_PP=0: the same segment order on all waves (A/B; measured 6-9 % slower: profiles/r04_tn_kernel_ab.txt)
     static const int pp = [] { const char* e = getenv("DDMP_TN_PP"); return e ? atoi(e) : 1; }();
-#define DDMP_L_(P_, G_, Q_) hipLaunchKernelGGL((gemm_tn_rm_kernel<P_, G_, Q_>), grid, block, 0, st, a)
+#define DDMP_L3_(P_, G_, Q_, TM_, TK_) hipLaunchKernelGGL((gemm_tn_rm_kernel<P_, G_, Q_, TM_, TK_>), grid, block, 0, st, a)
+#define DDMP_L_(P_, G_, Q_)                                                                       \
+    do {                                                                                          \
+        if (a.tm == 256 && a.tk == 256) DDMP_L3_(P_, G_, Q_, 256, 256);                           \
+        else if (a.tm == 256) DDMP_L3_(P_, G_, Q_, 256, 128);                                     \
+        else DDMP_L3_(P_, G_, Q_, 128, 256);                                                      \
+    } while (0)
     // (three operand streams: always the common order -- in the rotated loop hipcc puts a full vmcnt drain in front of the Z
     //  conversion, and measured the two forms tie: profiles/r04_tn_kernel_ab.txt)
     if (gdual) { if (pro) DDMP_L_(true, true, 0); else DDMP_L_(false, true, 0); }
     else if (pp == 0) { if (pro) DDMP_L_(true, false, 0); else DDMP_L_(false, false, 0); }
     else { if (pro) DDMP_L_(true, false, 1); else DDMP_L_(false, false, 1); }
+#undef DDMP_L3_
 #undef DDMP_L_
 }
 

@@ -7,7 +7,8 @@ from dual_dmp_amd import ops
 dev = torch.device("cuda:0")
 n = int(os.environ.get("ROWS", "1000000"))
 out = []
-for M, K in ((512, 512), (256, 256), (512, 256)):
+shapes = [tuple(int(x) for x in t.split("x")) for t in os.environ.get("TN_SHAPES", "512x512 256x256 512x256").split()]
+for M, K in shapes:
     dz = torch.randn(n, M, device=dev); yb = torch.randn(n, M, device=dev); z = torch.randn(n, K, device=dev)
     bn4 = torch.rand(4, M, device=dev) + 0.5; c10 = torch.rand(2, M, device=dev) * 0.1
     sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev)

@@ -240,7 +240,9 @@ GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6, 13: 2e-6}
                                    (21000, 96, 384), (20300, 64, 260), (66500, 320, 384), (70001, 64, 256),
                                    # narrow-output row panels (512-row blocks): M <= 32 | 64 | 128, K = 32 .. 256
                                    (20500, 32, 64), (33000, 64, 32), (21001, 256, 128), (25000, 128, 20), (20100, 64, 100),
-                                   (40000, 256, 512)])
+                                   (40000, 256, 512),
+                                   # wgrad panels of 256 x 128 and 128 x 256 (round 4: the 128 <-> 256 layers), ragged row counts
+                                   (40001, 128, 256), (66500, 256, 128)])
 def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
     from dual_dmp_amd import ops
     tol = GEMM_TOL[gemm_mode]
@@ -291,6 +293,28 @@ def test_gemm_bnbwd_fused_matches_composition(dev, n, cin, cout):
     ops.bn_bwd_apply(dzg, ybg, bn4g, c10g, dy, sums)
     assert relerr(dy, dy_ref) < 1e-6
     assert relerr(dx, ops.gemm_nn(dy, wg).double().cpu()) < 3e-6
+
+
+@pytest.mark.parametrize("n,M,K", [(65999, 128, 256), (40003, 256, 128), (33001, 128, 512)])
+def test_wgrad_narrow_panels_with_bn_backward_on_the_load(dev, n, M, K):
+    """Round 4: the f16x3 wgrad kernel's 256 x 128 / 128 x 256 panels in their three-stream form -- dW = dY^T . f(Z) with dY the
+    BatchNorm+LeakyReLU backward of (dZ, Yb) rebuilt on the load -- against float64, with and without the prologue on Z, at row
+    counts that leave a ragged last stage and a ragged last split."""
+    from dual_dmp_amd import ops
+    if not ops.gemm_tn_bnbwd_supported(M, K, n):
+        pytest.skip("fused wgrad not available in this GEMM mode")
+    torch.manual_seed(n + M)
+    dz, yb, z = torch.randn(n, M), torch.randn(n, M) * 2 + 0.5, torch.randn(n, K)
+    bn4 = torch.stack([torch.rand(M) + 0.5, torch.randn(M), torch.randn(M), torch.rand(M) + 0.5])
+    c10 = torch.stack([torch.randn(M) * 0.1, torch.randn(M) * 0.1])
+    a, b, k1, k0 = bn4[0].double(), bn4[1].double(), c10[0].double(), c10[1].double()
+    dy_ref = a * dz.double() * torch.where(yb.double() * a + b > 0, 1.0, 0.01) + k1 * yb.double() + k0
+    dzg, ybg, zg, bn4g, c10g = (t.to(dev) for t in (dz, yb, z, bn4, c10))
+    dw = ops.gemm_tn_bnbwd(dzg, ybg, zg, bn4g, c10g)
+    assert relerr(dw, dy_ref.t() @ z.double()) < 3e-6
+    sc, sh = (torch.rand(K) + 0.5).to(dev), torch.randn(K).to(dev)
+    dw = ops.gemm_tn_bnbwd(dzg, ybg, zg, bn4g, c10g, pro=(sc, sh))
+    assert relerr(dw, dy_ref.t() @ f_ref(z.double(), sc.cpu().double(), sh.cpu().double())) < 3e-6
 
 
 @pytest.mark.parametrize("cin", [16, 8])
