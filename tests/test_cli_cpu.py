@@ -200,7 +200,7 @@ def test_row_register_gemm_isa_audit():
 def test_wide_wgrad_isa_audit():
     """The wide f16x3 wgrad of round 4 (csrc/gemm_tn_rm.hip): what made its predecessor slow was invisible in the source --
     loads in exec-masked side blocks, vmcnt(0) before every use.  scripts/check_tn_asm.py compiles the file for gfx950 (device
-    only) and checks, for all six instantiations, that each main loop is ONE basic block holding its 48 MFMAs and all of its
+    only) and checks, for all 18 instantiations (three panel shapes), that each main loop is ONE basic block holding its 48 (24) MFMAs and all of its
     buffer loads, has no scratch traffic and no `s_waitcnt vmcnt(0)`."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -208,7 +208,7 @@ def test_wide_wgrad_isa_audit():
         pytest.skip("hipcc not installed")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_tn_asm.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "kernels audited: 6, problems: 0" in r.stdout
+    assert "kernels audited: 18, problems: 0" in r.stdout
 
 
 def test_bench_parity_object_bounds():
