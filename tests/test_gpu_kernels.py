@@ -242,7 +242,7 @@ GEMM_TOL = {6: 2e-6, 3: 3e-5, 0: 2e-6, 13: 2e-6}
                                    (20500, 32, 64), (33000, 64, 32), (21001, 256, 128), (25000, 128, 20), (20100, 64, 100),
                                    (40000, 256, 512),
                                    # wgrad panels of 256 x 128 and 128 x 256 (round 4: the 128 <-> 256 layers), ragged row counts
-                                   (40001, 128, 256), (66500, 256, 128)])
+                                   (40001, 128, 256), (66500, 256, 128), (40003, 128, 320), (40005, 384, 128)])     # (+ partial panels)
 def test_gemm_nt_nn_tn(dev, gemm_mode, n, K, M):
     from dual_dmp_amd import ops
     tol = GEMM_TOL[gemm_mode]
