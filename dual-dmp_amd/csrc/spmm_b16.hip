@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     // fused form measured slower than SpMM + reduction pass (round 2: 939 vs 457 + 390 us at C = 512)
     constexpr int kRedC = 1024;
     __shared__ __attribute__((aligned(16))) float s_red[RED == 1 ? 4 * kRedC : RED == 2 ? kRedC : 4];
+    __shared__ float s_part[RED ? 2 : 1][RED ? 4 : 1][RED ? 64 : 1];    // RED: the waves' partials of a slab (see the epilogue)
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -272,22 +273,29 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 }
             }
         }
-        if (RED) {                                               // per wave and chunk: one partial per channel
-#pragma unroll
-            for (int j = 0; j < VW; ++j)
+        if (RED) {                                               // per chunk: ONE partial record per channel (round 4: the four
+#pragma unroll                                                   // waves' sums meet in LDS -- a quarter of the partial traffic,
+            for (int j = 0; j < VW; ++j)                         // which was 17 % of the tensor bytes at C = 512 in bf16)
 #pragma unroll
                 for (int o = LANES; o < 64; o <<= 1) {
                     q0[j] += __shfl_xor(q0[j], o, 64);
                     q1[j] += __shfl_xor(q1[j], o, 64);
                 }
             if (grp == 0) {
-                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
 #pragma unroll
-                for (int q = 0; q < VW / 4; ++q) {
-                    *reinterpret_cast<float4*>(pp + 4 * q) = make_float4(q0[4 * q], q0[4 * q + 1], q0[4 * q + 2], q0[4 * q + 3]);
-                    *reinterpret_cast<float4*>(pp + C + 4 * q) = make_float4(q1[4 * q], q1[4 * q + 1], q1[4 * q + 2], q1[4 * q + 3]);
+                for (int j = 0; j < VW; ++j) {
+                    s_part[0][RED ? wave : 0][RED ? sl * VW + j : 0] = q0[j];
+                    s_part[RED ? 1 : 0][RED ? wave : 0][RED ? sl * VW + j : 0] = q1[j];
                 }
             }
+            __syncthreads();
+            if (tid < 2 * CS) {                                  // (waves in a fixed order, float64: the sums do not depend on timing)
+                const int which = tid / CS, c = tid % CS;
+                const double t = ((double)s_part[RED ? which : 0][0][RED ? c : 0] + (double)s_part[RED ? which : 0][RED ? 1 : 0][RED ? c : 0]) +
+                                 ((double)s_part[RED ? which : 0][RED ? 2 : 0][RED ? c : 0] + (double)s_part[RED ? which : 0][RED ? 3 : 0][RED ? c : 0]);
+                if (c0 + c < C) red.part[((int64_t)chunk * 2 + which) * C + c0 + c] = (float)t;
+            }
+            __syncthreads();
         }
     }
 }
@@ -387,11 +395,14 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
     BnRedB red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
     int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift, mean, rstd,
                               (float*)ws, st);
-    if (rc == ddmp::kPatchNotApplicable)
+    int red_groups = n_chunks * 4;                               // LDS-patch kernel: one record per wave and chunk
+    if (rc == ddmp::kPatchNotApplicable) {
         rc = dispatch_b16<false, true, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
+        red_groups = n_chunks;                                   // slab kernel: one record per chunk
+    }
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    fpartials_reduce((const float*)ws, red_groups, C, C, (double*)((char*)ws + pbytes), sums2, st);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -417,7 +428,7 @@ extern "C" int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int6
                              : dispatch_b16<false, 2, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
+    fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);    // (one record per chunk)
     LAUNCH_TRY();
     return DDMP_OK;
 }

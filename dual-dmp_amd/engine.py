@@ -506,10 +506,12 @@ class GcnEngine:
                      L.view(grads, "linear1.weight"), L.view(grads, "linear1.bias"),
                      L.view(grads, "linear2.weight"), L.view(grads, "linear2.bias"), n_rows=n)
         have_sums = False
-        # the backward column reductions from the SpMM epilogue: float32 features only.  With bf16 features the epilogue
-        # (one more row stream + 16 cross-lane sums per 128-byte slab) costs more than the separate pass it replaces
-        # (1M-face graph, C = 512: 939 us fused vs 457 + 390 us)
-        fuse_red = hasattr(ops, "spmm_bnred") and self.dtype == torch.float32
+        # the backward column reductions from the SpMM epilogue.  bf16 features: the epilogue (one more row stream + 16 cross-lane
+        # sums per 128-byte slab) used to cost as much as the separate pass it replaces (C = 512: 939 us fused vs 457 + 390 us);
+        # with one partial record per chunk (round 4) the step gains 0.27 ms (26.21 / 26.22 -> 25.97 / 25.92 ms, interleaved):
+        # on by default, DDMP_BF16_SPMM_BNRED=0 for A/B
+        fuse_red = hasattr(ops, "spmm_bnred") and (self.dtype == torch.float32
+                                                   or os.environ.get("DDMP_BF16_SPMM_BNRED", "1") != "0")
 
         def spmm_to_dz(src, dst, l):
             """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""
