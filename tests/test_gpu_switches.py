@@ -1,0 +1,67 @@
+"""The library's A/B switches are product configurations too: each one listed here runs ONE training
+iteration at 144,400 faces in its own process (the switches are read once per process) and must agree with the default build's
+iteration from the same weights to float32 rounding -- loss, outputs, gradients.  Same mathematics, other kernels / orders."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SWITCHES = [
+    {"DDMP_TN_NARROW_PANELS": "0"},            # 128 <-> 256 wgrads on the tiled bf16x6 kernel
+    {"DDMP_TN_PP": "0"},                       # wide wgrad: one segment order on all waves
+    {"DDMP_SPMM_PATCH": "0"},                  # lean gather everywhere
+    {"DDMP_SPMM_PATCH": "1"},                  # LDS-patch gather wherever it applies (incl. its fused-reduction form)
+    {"DDMP_SPMM_PATCH_NE": "0"},               # ... with the entries read from LDS per slab
+    {"DDMP_SPMM_LEAN": "0"},                   # round-2 slab gather
+    {"DDMP_GEMM_RR": "0"},                     # row-panel instead of row-register GEMMs
+    {"DDMP_GEMM_BNRED": "0"},                  # dgrad without the reductions epilogue
+    {"DDMP_BNBWD_NARROW": "0", "DDMP_BNBWD_L0": "0"},      # narrow layers: bn_bwd_apply + plain GEMMs
+    {"DDMP_SPMM_BNBWD": "0"},                  # transform-first layers: bn_bwd_apply + plain gather
+    {"DDMP_TAIL_FUSE": "0", "DDMP_PREP_WEIGHTS": "0"},
+    {"DDMP_GEMM_MODE": "6"},                   # bf16x6 everywhere
+]
+
+
+def _run(tmp, name, env_extra, dtype="f32"):
+    out = os.path.join(tmp, name + ".npz")
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("DDMP_") and k not in ("DDMP_LIB",):
+            del env[k]
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "switch_worker.py"), out, dtype], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (env_extra, r.stdout[-2000:], r.stderr[-3000:])
+    return dict(np.load(out))
+
+
+@pytest.fixture(scope="module")
+def baseline(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("switches"))
+    return tmp, _run(tmp, "default", {})
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_switch_agrees_with_the_default(baseline, env):
+    tmp, ref = baseline
+    got = _run(tmp, "_".join("%s%s" % kv for kv in env.items()), env)
+    assert np.isfinite(got["loss"]) and abs(got["loss"] - ref["loss"]) <= 3e-6 * abs(ref["loss"]), (got["loss"], ref["loss"])
+    assert np.abs(got["pos"] - ref["pos"]).max() <= 2e-5
+    assert np.abs(got["norm"] - ref["norm"]).max() <= 5e-4
+    for k in ("m0", "m1"):
+        assert np.linalg.norm(got[k] - ref[k]) <= 3e-4 * np.linalg.norm(ref[k]), k
+
+
+def test_bf16_switch_agrees_with_the_default(baseline):
+    """bf16 features: the backward reductions from the gather's epilogue (default since round 4) against the separate passes."""
+    tmp, _ = baseline
+    a = _run(tmp, "bf16_default", {}, "bf16")
+    b = _run(tmp, "bf16_sep", {"DDMP_BF16_SPMM_BNRED": "0"}, "bf16")
+    assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(b["loss"])
+    for k in ("m0", "m1"):
+        assert np.linalg.norm(a[k] - b[k]) <= 3e-2 * np.linalg.norm(b[k]), k
