@@ -24,6 +24,22 @@ SWITCHES = [
     {"DDMP_SPMM_BNBWD": "0"},                  # transform-first layers: bn_bwd_apply + plain gather
     {"DDMP_TAIL_FUSE": "0", "DDMP_PREP_WEIGHTS": "0"},
     {"DDMP_GEMM_MODE": "6"},                   # bf16x6 everywhere
+    {"DDMP_GEMM_PANEL": "0"},                  # tiled kernels instead of the row panels
+    {"DDMP_GEMM_WS": "0"},
+    {"DDMP_GEMM_BNRED_NARROW": "0"},
+    {"DDMP_RR_PM2_WIDE": "1"},                 # the two-half BatchNorm-backward dgrad on the row-register kernel
+    {"DDMP_SPMM_SLAB_GROUPS": "0"},
+    {"DDMP_SPMM_PATCH_MAXNNZ": "5"},           # LDS-patch gather on the face graph only
+    {"DDMP_SPMM_STATS": "0"},
+    {"DDMP_EQUAL_WIDTH": "transform"},
+]
+BF16_SWITCHES = [
+    {"DDMP_BF16_SPMM_BNRED": "0"},             # backward reductions as separate passes
+    {"DDMP_BF16_FUSE": "0"},                   # no BatchNorm backward on the GEMM operand loads
+    {"DDMP_TN_DMA": "0"},
+    {"DDMP_SPMM_B16_VW": "4"},
+    {"DDMP_GEMM_RR": "0"},
+    {"DDMP_SPMM_LEAN": "0"},
 ]
 
 
@@ -57,11 +73,18 @@ def test_switch_agrees_with_the_default(baseline, env):
         assert np.linalg.norm(got[k] - ref[k]) <= 3e-4 * np.linalg.norm(ref[k]), k
 
 
-def test_bf16_switch_agrees_with_the_default(baseline):
-    """bf16 features: the backward reductions from the gather's epilogue (default since round 4) against the separate passes."""
+@pytest.fixture(scope="module")
+def baseline_bf16(baseline):
     tmp, _ = baseline
-    a = _run(tmp, "bf16_default", {}, "bf16")
-    b = _run(tmp, "bf16_sep", {"DDMP_BF16_SPMM_BNRED": "0"}, "bf16")
-    assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(b["loss"])
+    return tmp, _run(tmp, "bf16_default", {}, "bf16")
+
+
+@pytest.mark.parametrize("env", BF16_SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_bf16_switch_agrees_with_the_default(baseline_bf16, env):
+    """bf16 features: the same iteration through the other kernels / the unfused passes -- bf16 rounding of intermediate tensors
+    differs between the routes, so the agreement is to bf16 accuracy."""
+    tmp, ref = baseline_bf16
+    got = _run(tmp, "bf16_" + "_".join("%s%s" % kv for kv in env.items()), env, "bf16")
+    assert np.isfinite(got["loss"]) and abs(got["loss"] - ref["loss"]) <= 5e-3 * abs(ref["loss"]), (got["loss"], ref["loss"])
     for k in ("m0", "m1"):
-        assert np.linalg.norm(a[k] - b[k]) <= 3e-2 * np.linalg.norm(b[k]), k
+        assert np.linalg.norm(got[k] - ref[k]) <= 5e-2 * np.linalg.norm(ref[k]), k
