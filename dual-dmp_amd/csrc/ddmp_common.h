@@ -95,12 +95,18 @@ struct ddmp_graph {
     int32_t* col;       // device [nnz]
     float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
     int max_row_nnz;
-    // per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR entry, the index of its
-    // column in that list -- what spmm_patch_dma_kernel stages through LDS (spmm.hip)
+    // LDS-patch gather (spmm_patch.hip).  Per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR
+    // entry, the index of its column in that list.  Selection is PER CHUNK: a chunk whose patch does not fit the kernel's
+    // buffers (more than 32 * patch_kd distinct columns), whose CSR slice does not fit its LDS tables, or that has no entries
+    // at all is "heavy": its pl_ptr span is empty, the patch kernel skips it and the lean gather processes the `heavy` list
+    // in a second (small) launch -- one hub vertex does not move a whole graph to another kernel.
     int32_t* pl_ptr;    // device [n_chunks + 1]
     int32_t* pl_col;    // device [pl_ptr[n_chunks]]
     uint16_t* lcol;     // device [nnz]
-    int max_patch;      // largest patch (0: tables not built)
+    int max_patch;      // largest patch among the chunks the patch kernel takes (0: tables not built)
+    int patch_kd;       // patch rows per LDS buffer / 32 (3..6), chosen so that at most ~1 % of the chunks are heavy
+    int32_t* heavy;     // device [n_heavy]: the heavy chunks, ascending
+    int n_heavy;
 };
 namespace ddmp {
 constexpr int kChunkRows = 64;

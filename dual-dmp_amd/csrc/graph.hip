@@ -88,6 +88,46 @@ extern "C" int ddmp_csr_bfs_order_host(int64_t n, const int32_t* rowptr, const i
     return DDMP_OK;
 }
 
+namespace {
+struct RcbCtx {
+    const double* p;
+    int leaf;
+};
+void rcb_split(const RcbCtx& c, int32_t* idx, int64_t m) {
+    while (m > c.leaf) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int64_t i = 0; i < m; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const double v = c.p[3 * (int64_t)idx[i] + a];
+                lo[a] = std::min(lo[a], v);
+                hi[a] = std::max(hi[a], v);
+            }
+        int ax = 0;
+        for (int a = 1; a < 3; ++a)
+            if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+        const int64_t leaves = (m + c.leaf - 1) / c.leaf;
+        const int64_t nl = (leaves / 2) * c.leaf;               // the left part: whole leaves
+        const double* p = c.p;
+        std::nth_element(idx, idx + nl, idx + m, [p, ax](int32_t u, int32_t v) {
+            const double a = p[3 * (int64_t)u + ax], b = p[3 * (int64_t)v + ax];
+            return a < b || (a == b && u < v);
+        });
+        rcb_split(c, idx, nl);                                  // (recursion depth <= log2(n / leaf))
+        idx += nl;
+        m -= nl;
+    }
+}
+}  // namespace
+
+extern "C" int ddmp_rcb_order_host(int64_t n, const double* xyz, int leaf, int32_t* order) {
+    ARG_TRY(n > 0 && n < (int64_t)INT32_MAX && xyz && order && leaf > 0);
+    for (int64_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+    for (int64_t i = 0; i < 3 * n; ++i)
+        if (!(xyz[i] == xyz[i])) return DDMP_EINVAL;            // NaN coordinates have no order
+    rcb_split(RcbCtx{xyz, leaf}, order, n);
+    return DDMP_OK;
+}
+
 static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
                         const float* dinv, ddmp_graph** out) {
     ddmp_graph* g = new (std::nothrow) ddmp_graph();
@@ -109,34 +149,71 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
     if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     {   // patch tables (see ddmp_graph): skipped when the rows of a chunk fan out too far (unordered numbering)
         const int64_t n_chunks = (n_rows + ddmp::kChunkRows - 1) / ddmp::kChunkRows;
-        std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, tmp;
-        std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1));
-        int max_patch = 0;
-        // tables for the LDS-patch gather (spmm_patch.hip): by default for the graphs it is selected on -- at most 8 entries
-        // per row (face and vertex graphs of a mesh), from 64k rows; DDMP_SPMM_PATCH=1 every graph (A/B), =0 none
+        // by default from 64k rows for graphs with at most 12 entries per row ON AVERAGE (mesh graphs: 4 and ~7; the LDS
+        // tables of a chunk hold 16 per row); DDMP_SPMM_PATCH=1 every graph (A/B), =0 none.  Row lengths are NOT a condition
+        // any more (round 5): long rows run their tail from LDS lists, oversized chunks go to the heavy list.
         const char* pe = getenv("DDMP_SPMM_PATCH");
         const int pm = pe ? atoi(pe) : 3;
-        bool ok = g->nnz > 0 && (pm == 1 || (pm != 0 && mx <= 8 && n_rows >= 65536));
-        for (int64_t c = 0; c < n_chunks && ok; ++c) {
-            const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
-            tmp.assign(col + rowptr[r0], col + rowptr[r1]);
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            if (tmp.size() > 4096) { ok = false; break; }
-            max_patch = std::max(max_patch, (int)tmp.size());
-            for (int64_t e2 = rowptr[r0]; e2 < rowptr[r1]; ++e2)
-                lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
-            pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
-            pl_ptr[(size_t)c + 1] = (int32_t)pl_col.size();
+        bool ok = g->nnz > 0 && (pm == 1 || (pm != 0 && g->nnz <= 12 * n_rows && n_rows >= 65536));
+        constexpr int kMaxE = ddmp::kChunkRows * 16, kMaxKd = 6;
+        std::vector<int32_t> np_of, tmp;
+        if (ok) {
+            np_of.assign((size_t)n_chunks, 0);
+            int64_t over = 0;                                    // chunks that cannot be taken even with the largest buffers
+            for (int64_t c = 0; c < n_chunks; ++c) {
+                const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
+                const int64_t ne = rowptr[r1] - rowptr[r0];
+                if (ne == 0 || ne > kMaxE) { np_of[(size_t)c] = ne == 0 ? 0 : INT32_MAX; over += ne != 0; continue; }
+                tmp.assign(col + rowptr[r0], col + rowptr[r1]);
+                std::sort(tmp.begin(), tmp.end());
+                const int np = (int)(std::unique(tmp.begin(), tmp.end()) - tmp.begin());
+                np_of[(size_t)c] = np;
+                over += np > 32 * kMaxKd;
+                if (c == 1023 && over > 512) { over = n_chunks; break; }     // an unordered numbering: stop counting
+            }
+            ok = over * 50 <= n_chunks;                          // more than 2 % oversized: not a graph for this kernel
         }
         if (ok) {
-            if ((e = hipMalloc((void**)&g->pl_ptr, sizeof(int32_t) * pl_ptr.size())) != hipSuccess) goto fail;
-            if ((e = hipMalloc((void**)&g->pl_col, sizeof(int32_t) * std::max<size_t>(pl_col.size(), 1))) != hipSuccess) goto fail;
-            if ((e = hipMalloc((void**)&g->lcol, sizeof(uint16_t) * lcol.size())) != hipSuccess) goto fail;
-            if ((e = hipMemcpy(g->pl_ptr, pl_ptr.data(), sizeof(int32_t) * pl_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
-            if ((e = hipMemcpy(g->pl_col, pl_col.data(), sizeof(int32_t) * pl_col.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
-            if ((e = hipMemcpy(g->lcol, lcol.data(), sizeof(uint16_t) * lcol.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
-            g->max_patch = max_patch;
+            int kd = 3;                                          // the smallest buffers that leave at most 1 % of the chunks heavy
+            for (; kd < kMaxKd; ++kd) {
+                int64_t heavy = 0;
+                for (int64_t c = 0; c < n_chunks; ++c) heavy += np_of[(size_t)c] > 32 * kd;
+                if (heavy * 100 <= n_chunks) break;
+            }
+            std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, heavy;
+            std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1), 0);
+            int max_patch = 0;
+            for (int64_t c = 0; c < n_chunks; ++c) {
+                const int np = np_of[(size_t)c];
+                if (np == 0 || np > 32 * kd) {
+                    heavy.push_back((int32_t)c);
+                } else {
+                    const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
+                    tmp.assign(col + rowptr[r0], col + rowptr[r1]);
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    max_patch = std::max(max_patch, (int)tmp.size());
+                    for (int64_t e2 = rowptr[r0]; e2 < rowptr[r1]; ++e2)
+                        lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
+                    pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
+                }
+                pl_ptr[(size_t)c + 1] = (int32_t)pl_col.size();
+            }
+            if (max_patch > 0) {
+                if ((e = hipMalloc((void**)&g->pl_ptr, sizeof(int32_t) * pl_ptr.size())) != hipSuccess) goto fail;
+                if ((e = hipMalloc((void**)&g->pl_col, sizeof(int32_t) * std::max<size_t>(pl_col.size(), 1))) != hipSuccess) goto fail;
+                if ((e = hipMalloc((void**)&g->lcol, sizeof(uint16_t) * lcol.size())) != hipSuccess) goto fail;
+                if ((e = hipMemcpy(g->pl_ptr, pl_ptr.data(), sizeof(int32_t) * pl_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                if ((e = hipMemcpy(g->pl_col, pl_col.data(), sizeof(int32_t) * pl_col.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                if ((e = hipMemcpy(g->lcol, lcol.data(), sizeof(uint16_t) * lcol.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                if (!heavy.empty()) {
+                    if ((e = hipMalloc((void**)&g->heavy, sizeof(int32_t) * heavy.size())) != hipSuccess) goto fail;
+                    if ((e = hipMemcpy(g->heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                }
+                g->n_heavy = (int)heavy.size();
+                g->max_patch = max_patch;
+                g->patch_kd = kd;
+            }
         }
     }
     *out = g;
@@ -189,6 +266,7 @@ extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
     if (g->pl_ptr) (void)hipFree(g->pl_ptr);
     if (g->pl_col) (void)hipFree(g->pl_col);
     if (g->lcol) (void)hipFree(g->lcol);
+    if (g->heavy) (void)hipFree(g->heavy);
     delete g;
     return DDMP_OK;
 }

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -358,11 +359,19 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
 #include "fpartials.inc"
 #include "spmm_lean.inc"
 
+// chunk_list / n_list: only these chunks (the LDS-patch kernel's heavy list), one workgroup each
 template <bool PRO, int RED, bool BWD>
 int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
                 const float* bias, const float* ps, const float* psh, float slope, hipStream_t st, BnRed red = BnRed(),
-                BnBwdGather bwd = BnBwdGather()) {
+                BnBwdGather bwd = BnBwdGather(), const int* chunk_list = nullptr, int n_list = 0) {
     const int n = (int)g->n_rows;
+    if (chunk_list) {
+        if (n_list <= 0) return DDMP_OK;
+        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
+                           Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
+        LAUNCH_TRY();
+        return DDMP_OK;
+    }
     const int cpx = (int)cdiv(lp.n_chunks, kXcd);
     // small graphs: split the slabs of a chunk over several workgroups (the staged CSR slice is cheap to repeat) until ~2048
     // workgroups exist -- a workgroup per 64 rows alone leaves a 13k-row graph with 205 long-running workgroups on 256 CUs
@@ -375,7 +384,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         groups = (n_slabs + per - 1) / per;
     }
     hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                       Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, lp.stride, red, bwd);
+                       Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, (const int*)nullptr, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -389,8 +398,8 @@ int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int6
     dim3 grid(cpx * kXcd), block(256);
     if (LANES == 8 && U == 4 && NR == 1 && SL == 1) {
         const LeanPlan lp = lean_plan(g, ldx, ldy, C);
-        if (lp.kind && ps) return launch_lean<true, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
-        if (lp.kind) return launch_lean<false, false, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
+        if (lp.kind && ps) return launch_lean<true, 0, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
+        if (lp.kind) return launch_lean<false, 0, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
     }
     if (ps)
         hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
@@ -437,10 +446,18 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
         const char* e = getenv("DDMP_SPMM");
         spmm_mode = (e && e[0] == 'r') ? 0 : (e && e[0] == 's' && e[1] == '1') ? 5 : 4;      // default: slab / lean kernels
     }
-    if (vec && spmm_mode >= 4) {                                 // LDS-patch kernel (spmm_patch.hip) where it applies
-        const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
-                                        nullptr, nullptr, nullptr, nullptr, st);
-        if (rc != ddmp::kPatchNotApplicable) return rc;
+    if (vec && spmm_mode >= 4 && C % 32 == 0) {                  // LDS-patch kernel (spmm_patch.hip) where it applies
+        const LeanPlan lp = lean_plan(g, ldx, ldy, C);           // (its heavy chunks are the lean gather's)
+        if (lp.kind || g->n_heavy == 0) {
+            const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
+                                            nullptr, nullptr, nullptr, nullptr, st);
+            if (rc == DDMP_OK && g->n_heavy > 0)
+                return pro_scale ? launch_lean<true, 0, false>(lp, g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, BnRed(),
+                                                               BnBwdGather(), g->heavy, g->n_heavy)
+                                 : launch_lean<false, 0, false>(lp, g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, BnRed(),
+                                                                BnBwdGather(), g->heavy, g->n_heavy);
+            if (rc != ddmp::kPatchNotApplicable) return rc;
+        }
     }
     if (vec && spmm_mode >= 4 && C >= 32 && C % 32 == 0) {
         // 4 gathers in flight per lane measured best (8 in flight -- one batch of 8, or two rows x 4 -- was 3-5 %
@@ -513,21 +530,24 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnRed red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
-    {
-        const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift,
-                                        mean, rstd, (float*)ws, st);
+    const LeanPlan lp = lean_plan(g, ldx, ldy, C, 2);
+    if (lp.kind || g->n_heavy == 0) {                            // LDS-patch kernel: one record per chunk, like the lean gather
+        int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift,
+                                  mean, rstd, (float*)ws, st);
+        if (rc == DDMP_OK && g->n_heavy > 0)
+            rc = launch_lean<false, 1, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red, BnBwdGather(),
+                                              g->heavy, g->n_heavy);
         if (rc == DDMP_OK) {
             const size_t pb2 = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-            fpartials_reduce((const float*)ws, n_chunks * 4, C, C, (double*)((char*)ws + pb2), sums2, st);
+            fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pb2), sums2, st);
             LAUNCH_TRY();
             return DDMP_OK;
         }
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
     int red_groups = n_chunks * 4;                               // slab kernel: one record per wave and chunk
-    const LeanPlan lp = lean_plan(g, ldx, ldy, C, 2);
     if (lp.kind) {
-        const int rc = launch_lean<false, true, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
+        const int rc = launch_lean<false, 1, false>(lp, g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
         if (rc != DDMP_OK) return rc;
         red_groups = lp.n_chunks;                                // lean kernel: one record per chunk
     } else {
@@ -589,8 +609,8 @@ extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnBwdGather bwd{Yb, ldyb, c1, c0};
-    const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, ld_out, C, 4) : LeanPlan{0, 0, 0};   // one staged offset serves both matrices
-    if (lp.kind) return launch_lean<true, false, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
+    const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, ld_out, C, 4) : LeanPlan{0, 0};   // one staged offset serves both matrices
+    if (lp.kind) return launch_lean<true, 0, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
                        (hipStream_t)stream, g->rowptr, g->col, g->dinv, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,
                        a, b, slope, cpx, n_chunks, BnRed(), bwd);

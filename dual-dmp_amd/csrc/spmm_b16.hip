@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -69,13 +70,14 @@ template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f
 // whole quads with weight-0 copies of their last entry -- so the address of a gathered piece is one v_lshl_add_u64 on the
 // lane's slab base and the inner loop reads four entries with two ds_read_b128, without clamping or branches.
 // RED: 0 | 1 BatchNorm-backward reductions of the output | 2 BatchNorm statistics of the (rounded) output around red.mean
-// (see spmm_lean.inc)
+// (see spmm_lean.inc).  Round 5: a row's slots are its own quads, packed per chunk (rows of any length; a chunk whose packed
+// slots exceed the LDS array reads its entries from global memory), `chunk_list` = the LDS-patch kernel's heavy chunks.
 template <int VW, int LANES, int U, bool PRO, int RED, bool BWD, bool LEAN>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
-    float slope, int chunks_per_xcd, int n_chunks, int stride, BnRedB red, BnBwdGatherB bwd) {
+    float slope, int chunks_per_xcd, int n_chunks, const int* __restrict__ chunk_list, BnRedB red, BnBwdGatherB bwd) {
     static_assert(!BWD || (PRO && !RED), "BWD: the coefficients a, b come as the prologue's");
     static_assert(!LEAN || U == 4, "quads");
     typedef Piece<VW> PC;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     constexpr int RPW = 64 / LANES;
     constexpr int RPB = 4 * RPW;
     __shared__ int s_rowptr[kRB + 1];
-    __shared__ int s_quads[kRB];
+    __shared__ int s_slot[kRB];                                  // LEAN: (first quad of the row's slots) * 512 + its quad count
     __shared__ __attribute__((aligned(16))) uint2 s_ent[kMaxE];  // LEAN: (offset, weight) slots; else: s_col | s_w
     int* s_col = reinterpret_cast<int*>(s_ent);
     float* s_w = reinterpret_cast<float*>(s_ent) + kMaxE;
@@ -94,8 +96,14 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     __shared__ __attribute__((aligned(16))) float s_red[RED == 1 ? 4 * kRedC : RED == 2 ? kRedC : 4];
     __shared__ float s_part[RED ? 2 : 1][RED ? 4 : 1][RED ? 64 : 1];    // RED: the waves' partials of a slab (see the epilogue)
 
-    const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
-    if (chunk >= n_chunks) return;
+    int chunk;
+    if (chunk_list) {
+        if ((int)blockIdx.x >= n_chunks) return;
+        chunk = chunk_list[blockIdx.x];
+    } else {
+        chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
+        if (chunk >= n_chunks) return;
+    }
     const int r0 = chunk * kRB;
     const int nr = min(kRB, n_rows - r0);
     const int tid = threadIdx.x;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     __syncthreads();
     const int e0 = s_rowptr[0];
     const int ne = s_rowptr[nr] - e0;
-    const bool staged = ne <= kMaxE;
+    bool staged = ne <= kMaxE;
     if (RED == 1) {
         for (int i = tid; i < C; i += 256) {
             const float rs = red.rstd[i];
@@ -115,19 +123,30 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     }
     if (RED == 2)
         for (int i = tid; i < C; i += 256) s_red[i] = red.mean[i];
+    const unsigned ld16 = (unsigned)(ldx >> 3);                  // row pitch in 16-byte units
     if (LEAN) {
-        const unsigned ld16 = (unsigned)(ldx >> 3);              // row pitch in 16-byte units
-        for (int i = tid; i < nr * stride; i += 256) {
-            const int lr = i / stride, k = i - lr * stride;
-            const int rb = s_rowptr[lr], nn = s_rowptr[lr + 1] - rb;
-            uint2 e = make_uint2(0u, 0u);
-            if (nn > 0) {                                        // padding: the row's last entry again, weight 0
+        // every wave: quad counts of the chunk's rows (lane = row), their exclusive prefix sum; thread t stages the slots
+        // k = t & 3, + 4, ... of row t >> 2 (see spmm_lean.inc)
+        const int ln = tid & 63;
+        const int nn_l = ln < nr ? s_rowptr[ln + 1] - s_rowptr[ln] : 0;
+        const int nq_l = (nn_l + 3) >> 2;
+        int incl = nq_l;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (ln >= o) incl += t;
+        }
+        const int qoff_l = incl - nq_l;
+        staged = __shfl(incl, 63, 64) * 4 <= kMaxE;              // (the same in every wave)
+        if (tid < nr) s_slot[tid] = staged ? qoff_l * 512 + nq_l : 0;
+        if (staged) {
+            const int lr = tid >> 2;
+            const int qo = __shfl(qoff_l, lr, 64), nq = __shfl(nq_l, lr, 64), nn = __shfl(nn_l, lr, 64);
+            const int rb = s_rowptr[min(lr, nr)];
+            for (int k = tid & 3; k < 4 * nq; k += 4) {          // padding: the row's last entry again, weight 0
                 const int c = col[rb + min(k, nn - 1)];
-                e.x = (unsigned)c * ld16;
-                e.y = k < nn ? __float_as_uint(dinv[c]) : 0u;
+                s_ent[4 * qo + k] = make_uint2((unsigned)c * ld16, k < nn ? __float_as_uint(dinv[c]) : 0u);
             }
-            s_ent[i] = e;
-            if (k == 0) s_quads[lr] = (nn + 3) >> 2;
         }
     } else if (staged) {
         for (int t = tid; t < ne; t += 256) {
@@ -140,6 +159,8 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
 
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LANES, sl = lane % LANES;
+    auto slabs = [&](auto slots_tag) {
+    constexpr bool SLOTS = decltype(slots_tag)::value;           // LEAN and the chunk's slots fit: entries from s_ent
     for (int c0 = 0; c0 < C; c0 += CS) {
         const int off = c0 + sl * VW;
         float pa[VW], pb[VW], k1[VW], k0[VW];
@@ -160,9 +181,10 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         const bf16_t* xc = X + off;
         const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
         for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
-            int es = LEAN ? 0 : s_rowptr[lr] - e0;
-            const int ee = LEAN ? 4 * s_quads[lr] : s_rowptr[lr + 1] - e0;
-            const uint4* ep = reinterpret_cast<const uint4*>(&s_ent[LEAN ? lr * stride : 0]);
+            const int sq = SLOTS ? s_slot[lr] : 0;
+            int es = SLOTS ? 0 : s_rowptr[lr] - e0;
+            const int ee = SLOTS ? 4 * (sq & 511) : s_rowptr[lr + 1] - e0;
+            const uint4* ep = reinterpret_cast<const uint4*>(&s_ent[SLOTS ? 4 * (sq >> 9) : 0]);
             float acc[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) acc[j] = 0.f;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 int cj[U];
                 float wj[U];
                 typename PC::raw v[U], vy[BWD ? U : 1];
-                if (LEAN) {
+                if (SLOTS) {
                     const uint4 ea = ep[es >> 1], eb = ep[(es >> 1) + 1];
                     const unsigned o[4] = {ea.x, ea.z, eb.x, eb.z};
                     wj[0] = __uint_as_float(ea.y);
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
 #pragma unroll
                     for (int k = 0; k < U; ++k) {
                         const int ek = min(es + k, ee - 1);
-                        if (staged) {
+                        if (!LEAN && staged) {
                             cj[k] = s_col[ek];
                             wj[k] = s_w[ek];
                         } else {
@@ -298,31 +320,40 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
             __syncthreads();
         }
     }
+    };
+    if (LEAN && staged) slabs(std::true_type());
+    else slabs(std::false_type());
 }
 
 #include "fpartials.inc"
 
+bool lean_b16_ok(const ddmp_graph* g, int64_t ldx) {             // offsets in 16-byte units fit 32 bits
+    return (ldx & 7) == 0 && (uint64_t)g->n_cols * (uint64_t)(ldx >> 3) < (1ull << 32);
+}
+
+// heavy / n_heavy: only these chunks (the LDS-patch kernel's heavy list), one workgroup each
 template <int VW, int LANES, bool PRO, int RED, bool BWD>
 int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
-               const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red, BnBwdGatherB bwd) {
+               const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red, BnBwdGatherB bwd,
+               const int* heavy = nullptr, int n_heavy = 0) {
     const int n = (int)g->n_rows;
-    const int n_chunks = (int)cdiv(n, kRB);
+    const int n_chunks = heavy ? n_heavy : (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
+    if (heavy && n_heavy <= 0) return DDMP_OK;
+    const dim3 grid(heavy ? n_heavy : cpx * kXcd);
     // lean staging where the rows fit their slots and the offsets (16-byte units) fit 32 bits; DDMP_SPMM_LEAN=0 for A/B
     static int lean_on = -1;
     if (lean_on < 0) {
         const char* e = getenv("DDMP_SPMM_LEAN");
         lean_on = (e && atoi(e) == 0) ? 0 : 1;
     }
-    const bool lean = lean_on && g->max_row_nnz >= 1 && g->max_row_nnz <= 16 && (ldx & 7) == 0 &&
-                      (uint64_t)g->n_cols * (uint64_t)(ldx >> 3) < (1ull << 32) && (!BWD || bwd.ldyb == ldx);
-    const int stride = (g->max_row_nnz + 3) & ~3;
+    const bool lean = lean_on && lean_b16_ok(g, ldx) && (!BWD || bwd.ldyb == ldx);
     if (lean)
-        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, stride, red, bwd);
+        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, true>), grid, dim3(256), 0, st, g->rowptr,
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     else
-        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, false>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, stride, red, bwd);
+        hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, false>), grid, dim3(256), 0, st, g->rowptr,
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -330,7 +361,7 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
 template <bool PRO, int RED, bool BWD>
 int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                  const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red = BnRedB(),
-                 BnBwdGatherB bwd = BnBwdGatherB()) {
+                 BnBwdGatherB bwd = BnBwdGatherB(), const int* heavy = nullptr, int n_heavy = 0) {
     // DDMP_SPMM_B16_VW=4 (A/B): 8-byte pieces in the fused forms.  Measured SLOWER although it restores full occupancy
     // (1M-face graph, C = 512: prologue form 771 vs 613 us, reduction form 1043 vs 999 us): these forms are bound by
     // instructions issued per gathered byte (index / weight reads, 64-bit addresses, unpack + 4 VALU per element), and
@@ -342,15 +373,15 @@ int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, i
     }
     constexpr bool kFused = PRO || RED != 0 || BWD;
     if (kFused && vw_fused == 4) {
-        if (C % 64 == 0) return launch_b16<4, 16, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-        if (C % 32 == 0) return launch_b16<4, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-        if (C % 16 == 0) return launch_b16<4, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-        return launch_b16<4, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+        if (C % 64 == 0) return launch_b16<4, 16, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+        if (C % 32 == 0) return launch_b16<4, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+        if (C % 16 == 0) return launch_b16<4, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+        return launch_b16<4, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
     }
-    if (C % 64 == 0) return launch_b16<8, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    if (C % 32 == 0) return launch_b16<8, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    if (C % 16 == 0) return launch_b16<8, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
-    return launch_b16<8, 1, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd);
+    if (C % 64 == 0) return launch_b16<8, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+    if (C % 32 == 0) return launch_b16<8, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+    if (C % 16 == 0) return launch_b16<8, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
+    return launch_b16<8, 1, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
 }
 
 bool shape_ok(const void* X, int64_t ldx, const void* Y, int64_t ldy, int C) {
@@ -370,10 +401,16 @@ extern "C" int ddmp_spmm_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ld
     {
         const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
                                         nullptr, nullptr, nullptr, nullptr, st);
+        if (rc == DDMP_OK && g->n_heavy > 0) {                   // its heavy chunks: the slab kernel over the list
+            if (pro_scale) return dispatch_b16<true, 0, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, BnRedB(),
+                                                               BnBwdGatherB(), g->heavy, g->n_heavy);
+            return dispatch_b16<false, 0, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, BnRedB(), BnBwdGatherB(),
+                                                 g->heavy, g->n_heavy);
+        }
         if (rc != ddmp::kPatchNotApplicable) return rc;
     }
-    if (pro_scale) return dispatch_b16<true, false, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-    return dispatch_b16<false, false, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st);
+    if (pro_scale) return dispatch_b16<true, 0, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
+    return dispatch_b16<false, 0, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st);
 }
 
 extern "C" size_t ddmp_spmm_bnred_bf16_workspace_bytes(int64_t n_rows, int C) {
@@ -395,14 +432,14 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
     BnRedB red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
     int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift, mean, rstd,
                               (float*)ws, st);
-    int red_groups = n_chunks * 4;                               // LDS-patch kernel: one record per wave and chunk
-    if (rc == ddmp::kPatchNotApplicable) {
-        rc = dispatch_b16<false, true, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
-        red_groups = n_chunks;                                   // slab kernel: one record per chunk
-    }
+    if (rc == DDMP_OK && g->n_heavy > 0)
+        rc = dispatch_b16<false, 1, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red, BnBwdGatherB(), g->heavy,
+                                           g->n_heavy);
+    if (rc == ddmp::kPatchNotApplicable)
+        rc = dispatch_b16<false, 1, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, red_groups, C, C, (double*)((char*)ws + pbytes), sums2, st);
+    fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st);    // (one record per chunk, both kernels)
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -439,5 +476,5 @@ extern "C" int ddmp_spmm_bnbwd_bf16(const ddmp_graph* g, const uint16_t* dZ, int
     ARG_TRY(g && dZ && Yb && out && a && b && c1 && c0 && dZ != out && Yb != out && shape_ok(dZ, lddz, out, ld_out, C));
     ARG_TRY(ldyb >= C && ldyb % 8 == 0 && b16_aligned(Yb) && coef_ok(a) && coef_ok(b) && coef_ok(c1) && coef_ok(c0));
     BnBwdGatherB bwd{Yb, ldyb, c1, c0};
-    return dispatch_b16<true, false, true>(g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRedB(), bwd);
+    return dispatch_b16<true, 0, true>(g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRedB(), bwd);
 }

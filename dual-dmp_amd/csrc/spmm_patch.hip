@@ -21,6 +21,7 @@
 #include "b16_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -64,10 +65,13 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 // KD: copies per wave and slab of the patch (8 rows each, 4 waves): the patch buffer holds 32 KD rows
 // NB: patch buffers (2: 41-57 KB of LDS per workgroup, two to three workgroups per CU hide each other's copy latency and
 // barriers; 4: the round-2 form, one workgroup per CU pipelining three slabs ahead)
-// NE: 0 = entries read from LDS per slab (any row length) | 4, 8 = every row of the graph has at most NE entries: a lane keeps
-// the patch offsets and weights of its two rows' entries in REGISTERS for all slabs of the chunk (round 4: the index and weight
-// reads were two of the three LDS instructions per gathered row; without them the 7-entry vertex graph went from 547 to 447 us
-// at C = 512 in a timing-only build), the gather of a slab is then NE ds_read_b128 with immediate buffer offsets per row
+// NE: 0 = entries read from LDS per slab | 4, 8 = a lane keeps the patch offsets and weights of the FIRST NE entries of its two
+// rows in REGISTERS for all slabs of the chunk (round 4: the index and weight reads were two of the three LDS instructions per
+// gathered row; without them the 7-entry vertex graph went from 547 to 447 us at C = 512 in a timing-only build), the gather
+// of a slab is then NE ds_read_b128 with immediate buffer offsets per row.  Round 5: rows LONGER than NE entries (irregular
+// meshes: valence 3 ... 12+) continue from the LDS lists -- the same sums in the same order --, behind a wave-uniform test that
+// a wave of short rows never enters; chunks the kernel cannot take at all (ddmp_graph: "heavy") return at once and are
+// computed by the lean gather.  Rows without entries (csr_host graphs) are legal: weight 0 on patch row 0.
 template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
@@ -79,10 +83,12 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     constexpr int PR = 32 * KD;                                  // patch rows per buffer
     constexpr int KR = RED ? 2 : 0;                              // copies per wave and slab of the chunk's own Yp rows
     constexpr int NST = 2;                                       // output stores per lane and slab
+    constexpr int NSR = RED ? 1 : 0;                             // + the wave's quarter of the previous slab's partial record
     constexpr int kBuf = PR * 128 + (RED ? kRB * 128 : 0);       // bytes per buffer
     constexpr int kNB = NB;
-    constexpr int NWAIT = (KD + KR) * (kNB - 2) + NST * (kNB - 1);   // VMEM operations younger than the copies of slab s
+    constexpr int NWAIT = (KD + KR) * (kNB - 2) + (NST + NSR) * (kNB - 1);   // VMEM operations younger than the copies of slab s
     static_assert(NWAIT <= 63, "vmcnt range");
+    static_assert(!RED || NB == 2, "the fused reduction's record stores are counted for two buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* bufs = smem;                                  // [kNB][kBuf]
     float* s_w = reinterpret_cast<float*>(smem + kNB * kBuf);    // [kMaxE]
@@ -91,6 +97,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     int* s_pl = s_rowptr + kRB + 4;                              // [PR]
     unsigned short* s_lc = reinterpret_cast<unsigned short*>(s_pl + PR);      // [kMaxE]
     float* s_coef = reinterpret_cast<float*>(s_lc + kMaxE);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd
+    // RED: the four waves' partial sums of a slab, by slab parity: [2][4 waves][2 sums][CS]
+    float* s_part = s_coef + (RED ? 7 : PRO ? 3 : 1) * C;
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -104,6 +112,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
     for (int i = tid; i < nr; i += 256) s_dinv[i] = dinv[r0 + i];
     const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
+    if (np <= 0) return;                                         // a heavy chunk: the lean gather's (uniform: before any barrier)
     for (int i = tid; i < PR; i += 256) s_pl[i] = pl_col[p0 + min(i, np - 1)];      // padded with the last row
     for (int i = tid; i < C; i += 256) {
         s_coef[i] = bias ? bias[i] : 0.f;
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     constexpr int NEc = NE > 0 ? NE : 1;
     int lo[2][NEc];
     float wjr[2][NEc];
+    int tail_es[2] = {0, 0}, tail_ee[2] = {0, 0};                // NE > 0: the entries behind the first NE of the lane's rows
     int nmax = 0;                                                // most entries of a row of this WAVE (uniform)
     if (NE > 0) {
 #pragma unroll
@@ -141,10 +151,12 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             const int es = s_rowptr[lrc] - e0;
             const int nn = lr < nr ? s_rowptr[lrc + 1] - s_rowptr[lrc] : 0;
             nmax = max(nmax, nn);
+            tail_es[q] = es + min(nn, NEc);
+            tail_ee[q] = es + nn;
 #pragma unroll
             for (int k = 0; k < NEc; ++k) {
-                const int ek = es + min(k, max(nn, 1) - 1);
-                lo[q][k] = (int)s_lc[ek] * 128 + sl * 16;
+                const int ek = es + min(k, nn - 1);              // missing entries: the row's last one again, weight 0
+                lo[q][k] = (nn > 0 ? (int)s_lc[ek] * 128 : 0) + sl * 16;     // (an empty row: patch row 0, weight 0)
                 wjr[q][k] = k < nn ? s_w[ek] : 0.f;
             }
         }
@@ -181,6 +193,17 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
 #pragma unroll
     for (int i = 0; i < kNB - 1; ++i)
         if (i < n_slabs) copy(i, bufs + i * kBuf);
+    // RED: ONE partial record per channel and chunk (as the lean gather writes them): the four waves' sums of slab s meet in
+    // LDS, every wave adds them up for a quarter of the slab's 2 CS values (fixed order, float64, rounded once) and stores
+    // that quarter -- one VMEM store per wave and slab, counted in the waits above
+    auto record = [&](int s) {
+        constexpr int Q = 2 * CS / 4;                            // values per wave
+        const int i = wave * Q + (lane % Q);                     // (lanes >= Q repeat a value; only the first Q store)
+        const int which = i / CS, c = i % CS;
+        const float* sp = s_part + ((s & 1) * 4 * 2) * CS + which * CS + c;
+        const double t = ((double)sp[0] + (double)sp[2 * CS]) + ((double)sp[4 * CS] + (double)sp[6 * CS]);
+        if (lane < Q) red.part[((int64_t)chunk * 2 + which) * C + s * CS + c] = (float)t;
+    };
     auto slab = [&](int s, auto bc) {
         constexpr int B = decltype(bc)::value;
         // the copies of slab s have landed (mine: counted wait; everybody's: barrier); all waves are done with slab s-1
@@ -189,10 +212,11 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         constexpr int ND = (KD + KR) * (kNB - 2);
         if (!full || s + kNB - 1 > n_slabs) wait_vm_barrier<0>();
         else if (s == 0) wait_vm_barrier<ND>();
-        else if (s == 1 && kNB > 2) wait_vm_barrier<ND + NST>();
+        else if (s == 1 && (kNB > 2 || RED)) wait_vm_barrier<ND + NST>();    // (RED: slab 0 had no record to store)
         else if (s == 2 && kNB > 3) wait_vm_barrier<ND + 2 * NST>();
         else wait_vm_barrier<NWAIT>();
         if (s + kNB - 1 < n_slabs) copy(s + kNB - 1, bufs + ((B + kNB - 1) % kNB) * kBuf);
+        if (RED && s > 0) record(s - 1);                         // (every wave's partials of slab s-1 are in LDS: the barrier above)
         const unsigned char* pb = bufs + B * kBuf + sl * 16;
         const int off = s * CS + sl * VW;
         float pa[VW], psh[VW], bs[VW];
@@ -215,8 +239,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             const int lr = wave * 8 + grp + 32 * q;
             const bool on = lr < nr;
             const int lrc = min(lr, nr - 1);
-            int es = s_rowptr[lrc] - e0;
-            const int ee = on ? s_rowptr[lrc + 1] - e0 : es;
+            int es = NE > 0 ? 0 : s_rowptr[lrc] - e0;
+            const int ee = NE > 0 ? tail_ee[q] : (on ? s_rowptr[lrc + 1] - e0 : es);
             float acc[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) acc[j] = 0.f;
@@ -239,7 +263,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                         }
                     }
                 }
-                es = ee;
+                es = nmax > NEc ? tail_es[q] : ee;               // (uniform test: long rows continue from the LDS lists)
             }
             while (es < ee) {
                 int li[4];
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                 }
             }
         }
-        if (RED) {
+        if (RED) {                                               // this wave's 16 rows -> LDS; the record: next slab (record())
 #pragma unroll
             for (int j = 0; j < VW; ++j)
 #pragma unroll
@@ -296,11 +320,11 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                     q1[j] += __shfl_xor(q1[j], o, 64);
                 }
             if (grp == 0) {
-                float* pp = red.part + ((int64_t)(chunk * 4 + wave) * 2) * C + off;
+                float* sp = s_part + (((s & 1) * 4 + wave) * 2) * CS + sl * VW;
 #pragma unroll
-                for (int q = 0; q < VW / 4; ++q) {
-                    *reinterpret_cast<float4*>(pp + 4 * q) = make_float4(q0[4 * q], q0[4 * q + 1], q0[4 * q + 2], q0[4 * q + 3]);
-                    *reinterpret_cast<float4*>(pp + C + 4 * q) = make_float4(q1[4 * q], q1[4 * q + 1], q1[4 * q + 2], q1[4 * q + 3]);
+                for (int j = 0; j < VW; ++j) {
+                    sp[j] = q0[j];
+                    sp[CS + j] = q1[j];
                 }
             }
         }
@@ -314,6 +338,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         if constexpr (kNB > 3) {
             if (s + 3 < n_slabs) slab(s + 3, std::integral_constant<int, 3>());
         }
+    }
+    if (RED) {
+        __syncthreads();
+        record(n_slabs - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
 }
@@ -331,7 +359,9 @@ template <typename T, int KD, bool PRO, bool RED, int NB>
 size_t patch2_lds(int C) {
     const int PR = 32 * KD;
     const size_t buf = (size_t)PR * 128 + (RED ? kRB * 128 : 0);
-    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4;
+    const size_t cs = 128 / sizeof(T);
+    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4 +
+           (RED ? 2 * 4 * 2 * cs * 4 : 0);
 }
 
 template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
@@ -342,10 +372,18 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
     const int cpx = (int)cdiv(n_chunks, kXcd);
     const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C);   // (the same for every NE)
     auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB, NE>;
-    static bool attr_done = false;                               // > 64 KB of dynamic LDS needs the attribute once per kernel
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    // > 64 KB of dynamic LDS needs the attribute, once per kernel AND device (a second device of the same process -- threaded
+    // ranks -- has its own copy of the function)
+    static std::atomic<uint32_t> attr_done{0};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 32) return ddmp::kPatchNotApplicable;
+    if (!(attr_done.load(std::memory_order_acquire) & (1u << dev))) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            return ddmp::kPatchNotApplicable;
+        }
+        attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->pl_ptr, g->pl_col, X,
                        ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
@@ -362,19 +400,21 @@ template <typename T, int KD, bool PRO, bool RED>
 int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                   const float* psh, float slope, hipStream_t st, RedArgs red) {
     // (the A/B buffer counts keep the LDS-entry form)
-    if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-    if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if constexpr (!RED) {
+        if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+        if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    }
+    // register entries: 4 where no row has more (face graphs), else 8 with the longer rows' tails from LDS (round 5)
     if (patch_ne() && g->max_row_nnz <= 4) return launch_patch2nb<T, KD, PRO, RED, 2, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-    if (patch_ne() && g->max_row_nnz <= 8) return launch_patch2nb<T, KD, PRO, RED, 2, 8>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    if (patch_ne()) return launch_patch2nb<T, KD, PRO, RED, 2, 8>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
     return launch_patch2nb<T, KD, PRO, RED, 2, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
 template <typename T, bool PRO, bool RED>
 int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
              const float* psh, float slope, hipStream_t st, RedArgs red) {
-    const int kd = (g->max_patch + 31) / 32;
-    switch (kd) {
-        case 1: case 2: case 3: return launch_patch2<T, 3, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
+    switch (g->patch_kd) {                                       // (chosen per graph: ddmp_graph, graph.hip)
+        case 3: return launch_patch2<T, 3, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
         case 4: return launch_patch2<T, 4, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
         case 5: return launch_patch2<T, 5, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
         case 6: return launch_patch2<T, 6, PRO, RED>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
@@ -392,7 +432,7 @@ int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, in
 // selection that follows from this (float32, rows of <= 8 entries, plain C >= 256 | prologue 256 <= C < 512), 0 = never,
 // 1 = wherever it applies (A/B runs).
 int patch_max_nnz() {                                             // DDMP_SPMM_PATCH_MAXNNZ=5: the face graph only (A/B)
-    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_MAXNNZ"); return (e && atoi(e) > 0) ? atoi(e) : 8; }();
+    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_MAXNNZ"); return (e && atoi(e) > 0) ? atoi(e) : (1 << 30); }();
     return v;
 }
 int patch_mode() {
@@ -409,9 +449,9 @@ int patch_mode() {
 
 // does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
 extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red) {
-    if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || g->max_row_nnz > kMaxE / kRB || !g->lcol) return 0;
-    // (measured selection, see by_patch's note: float32, no fused reduction, rows of at most 8 entries -- the register-entry form --,
-    //  plain C >= 256, prologue 256 <= C < 512)
+    if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || !g->lcol) return 0;
+    // (measured selection, see by_patch's note: float32, no fused reduction, plain C >= 256, prologue 256 <= C < 512; row lengths
+    //  are not a condition since round 5 -- DDMP_SPMM_PATCH_MAXNNZ=n keeps the A/B switch "graphs with longer rows stay lean")
     if (patch_mode() == 3 && (dtype != DDMP_F32 || has_red || g->max_row_nnz > patch_max_nnz() || C < 256 || (has_pro && C >= 512))) return 0;
     const int cs = dtype == DDMP_BF16 ? 64 : 32;
     return (C % cs == 0 && C >= 2 * cs && C <= 1024) ? 1 : 0;

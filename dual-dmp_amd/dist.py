@@ -56,6 +56,20 @@ def morton_order(points: np.ndarray) -> np.ndarray:
     return np.argsort(code, kind="stable")
 
 
+def rcb_order(points: np.ndarray, leaf: int = 64) -> np.ndarray:
+    """Recursive coordinate bisection of `points` [n,3] into leaves of `leaf` consecutive ids (new id -> old id): every
+    leaf -- and every aligned group of 2, 4, ... leaves -- is a compact patch of the surface.  Host code of the library
+    (``ddmp_rcb_order_host``, csrc/graph.hip); called through ctypes directly so that it also serves the CPU tests that
+    replace ``ops`` by a stand-in."""
+    import ctypes  # noqa: F401
+    from . import _lib
+    p = np.ascontiguousarray(points, dtype=np.float64)
+    assert p.ndim == 2 and p.shape[1] == 3
+    order = np.zeros(len(p), np.int32)
+    _lib.check(_lib.lib().ddmp_rcb_order_host(len(p), p.ctypes.data, int(leaf), order.ctypes.data), "ddmp_rcb_order_host")
+    return order.astype(np.int64)
+
+
 def face_owner_morton(fc: np.ndarray, P: int) -> np.ndarray:
     """P contiguous chunks of the Morton order of the face centroids, balanced on faces."""
     order = morton_order(fc)

@@ -278,6 +278,17 @@ def bfs_order_host(rowptr: np.ndarray, col: np.ndarray) -> np.ndarray:
     return order
 
 
+def rcb_order_host(points: np.ndarray, leaf: int = 64) -> np.ndarray:
+    """Recursive-coordinate-bisection node order (new id -> old id) of ``points`` [n,3]: leaves of ``leaf`` consecutive
+    ids are compact patches of the surface (ddmp_rcb_order_host; host code, no GPU needed)."""
+    p = np.ascontiguousarray(points, dtype=np.float64)
+    if p.ndim != 2 or p.shape[1] != 3:
+        raise DdmpError("rcb_order_host: points must be [n,3]")
+    order = np.zeros(len(p), np.int32)
+    check(_lib.lib().ddmp_rcb_order_host(len(p), p.ctypes.data, int(leaf), order.ctypes.data), "ddmp_rcb_order_host")
+    return order
+
+
 # ---------------------------------------------------------------------------------------- kernels
 def spmm(g: Graph, x, out=None, bias=None, pro=None, slope=SLOPE):
     """out[i] = dinv_i * sum_j dinv_j f(x[j]) (+bias); x has g.n_cols rows, out g.n_rows rows."""

@@ -158,6 +158,17 @@ def morton_relabel(vs, faces):
     return vs2, f2[fo]
 
 
+def rcb_relabel(vs, faces, leaf=64):
+    """Relabel vertices and faces by recursive coordinate bisection (``dist.rcb_order``): every 64 consecutive ids are a
+    compact patch -- the numbering the engines apply internally since round 5."""
+    from .dist import rcb_order
+    vo = rcb_order(vs, leaf)
+    inv = np.empty_like(vo)
+    inv[vo] = np.arange(len(vo))
+    vs2, f2 = vs[vo], inv[faces]
+    return vs2, f2[rcb_order(vs2[f2].mean(1), leaf)]
+
+
 def permute_faces(faces, seed=0):
     rng = np.random.default_rng(seed)
     return faces[rng.permutation(len(faces))]
@@ -209,3 +220,148 @@ def write_dataset_dir(root, name, gt, noisy, smooth):
     noisy.save(os.path.join(d, name + "_noise.obj"))
     smooth.save(os.path.join(d, name + "_smooth.obj"))
     return d
+
+
+# --------------------------------------------------------- irregular valence
+# The generators above are regular: every vertex of the torus / grid has valence 6 (the icosphere keeps twelve of valence
+# 5).  Meshes the reference is run on (scans, non-CAD models: README.md:57-67; util/mesh.py:189-197 accepts any valence)
+# are not, and the gather kernels' fast paths depend on the rows' lengths.  Two ways to get there from any closed mesh:
+# random manifold-preserving edge flips (a valence spread like a decimated scan's, 3 ... 12+) and a "hub" vertex grown
+# by targeted flips (a pole / cone apex).  Both keep V, F and the surface's topology; vertex positions are untouched.
+def _flip_candidates(faces, nv):
+    """Interior edges of an oriented manifold mesh as (f0, s0, f1, s1, A, B, C, D): half-edge A->B is slot s0 of
+    face f0 = (A, B, C), its twin B->A slot s1 of face f1 = (B, A, D)."""
+    a = faces[:, [0, 1, 2]].reshape(-1)
+    b = faces[:, [1, 2, 0]].reshape(-1)
+    c = faces[:, [2, 0, 1]].reshape(-1)
+    key = np.minimum(a, b) * np.int64(nv) + np.maximum(a, b)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    start = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+    sizes = np.diff(np.r_[start, len(ks)])
+    two = start[sizes == 2]
+    h0, h1 = order[two], order[two + 1]
+    ok = (a[h1] == b[h0]) & (b[h1] == a[h0]) & (c[h0] != c[h1])          # consistently oriented, not a folded pair
+    h0, h1 = h0[ok], h1[ok]
+    return h0 // 3, h0 % 3, h1 // 3, h1 % 3, a[h0], b[h0], c[h0], c[h1], ks[start]
+
+
+def _flip_ok(vs, A, B, C, D, min_quality=0.15):
+    """Geometric sanity of replacing (A,B,C), (B,A,D) by (A,D,C), (D,B,C): the quad is convex in its own plane and
+    neither new triangle is a sliver (area >= min_quality x the smaller old area)."""
+    def nrm(p, q, r):
+        return np.cross(vs[q] - vs[p], vs[r] - vs[p])
+    n0, n1 = nrm(A, B, C), nrm(B, A, D)
+    m0, m1 = nrm(A, D, C), nrm(D, B, C)
+    ref = n0 + n1
+    a_old = np.minimum(np.linalg.norm(n0, axis=1), np.linalg.norm(n1, axis=1))
+    a_new = np.minimum(np.linalg.norm(m0, axis=1), np.linalg.norm(m1, axis=1))
+    return ((m0 * ref).sum(1) > 0) & ((m1 * ref).sum(1) > 0) & (a_new >= min_quality * a_old)
+
+
+def flip_edges(vs, faces, rounds: int = 10, seed: int = 0, min_valence: int = 3, max_valence: int = 0):
+    """Random manifold-preserving edge flips.  Each round picks a vertex-disjoint random set of interior edges whose flip
+    keeps every valence >= ``min_valence`` (and <= ``max_valence`` if given), does not duplicate an existing edge and
+    keeps the quad geometrically sane; ~10 rounds turn a valence-6 torus into a mesh with valences 3 ... 12+.
+    -> new faces [F,3] (vs unchanged)."""
+    faces = np.array(faces, dtype=np.int64)
+    nv = len(vs)
+    rng = np.random.default_rng(seed)
+    for _ in range(rounds):
+        f0, s0, f1, s1, A, B, C, D, ekeys = _flip_candidates(faces, nv)
+        val = np.bincount(np.concatenate([ekeys // nv, ekeys % nv]), minlength=nv)
+        newkey = np.minimum(C, D) * np.int64(nv) + np.maximum(C, D)
+        ok = (val[A] > min_valence) & (val[B] > min_valence) & ~np.isin(newkey, ekeys) & _flip_ok(vs, A, B, C, D)
+        if max_valence:
+            ok &= (val[C] < max_valence) & (val[D] < max_valence)
+        cand = np.flatnonzero(ok)
+        chosen = []
+        for _pass in range(4):                                   # Luby passes: winners = local maxima of a random priority
+            if len(cand) == 0:
+                break
+            pr = rng.random(len(cand))
+            best = np.zeros(nv)
+            quad = np.stack([A[cand], B[cand], C[cand], D[cand]])
+            for q in quad:
+                np.maximum.at(best, q, pr)
+            win = (best[quad] == pr[None, :]).all(0)
+            chosen.append(cand[win])
+            taken = np.zeros(nv, dtype=bool)
+            taken[quad[:, win].reshape(-1)] = True
+            cand = cand[~win & ~taken[quad].any(0)]
+        if not chosen:
+            break
+        w = np.concatenate(chosen)
+        faces[f0[w]] = np.stack([A[w], D[w], C[w]], 1)
+        faces[f1[w]] = np.stack([D[w], B[w], C[w]], 1)
+    return faces
+
+
+def add_hub(vs, faces, vertex: int = 0, valence: int = 24):
+    """Grow ``vertex`` to the given valence by flipping, one at a time, an edge opposite to it in one of its incident
+    faces (each such flip adds the far vertex to its 1-ring).  Connectivity only: the hub's faces become long and thin,
+    which is what a pole or a cone apex looks like.  -> new faces [F,3]."""
+    faces = np.array(faces, dtype=np.int64)
+    nv = len(vs)
+    h = int(vertex)
+    order = np.argsort(faces.reshape(-1), kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(faces.reshape(-1), minlength=nv))])
+    vf = {}                                                      # vertex -> set of incident faces, built on demand
+
+    def inc(u):
+        st = vf.get(u)
+        if st is None:
+            st = vf[u] = set((order[ptr[u]:ptr[u + 1]] // 3).tolist())
+        return st
+
+    grown = True
+    while grown and len(inc(h)) < valence:
+        grown = False
+        ring = set(int(x) for f in inc(h) for x in faces[f])
+        for f in sorted(inc(h)):
+            tri = faces[f]
+            k = int(np.flatnonzero(tri == h)[0])
+            a, b = int(tri[(k + 1) % 3]), int(tri[(k + 2) % 3])          # face (h, a, b): flip its edge a-b
+            g = (inc(a) & inc(b)) - {f}
+            if len(g) != 1:
+                continue
+            g = g.pop()
+            t2 = faces[g]
+            d = int(t2[(t2 != a) & (t2 != b)][0])
+            if d in ring or len(inc(a)) <= 3 or len(inc(b)) <= 3:
+                continue
+            faces[f] = (h, a, d)
+            faces[g] = (h, d, b)
+            inc(a).discard(g)                                    # f keeps a, g keeps b; h and d are in both now
+            inc(b).discard(f)
+            inc(h).add(g)
+            inc(d).add(f)
+            grown = True
+            break
+    return faces
+
+
+def uv_sphere(n_seg: int, n_ring: int, modulate: float = 0.1):
+    """Latitude / longitude sphere: two poles of valence ``n_seg`` (the everyday high-valence vertex), every other vertex of
+    valence 6.  V = n_seg * (n_ring - 1) + 2, F = 2 * n_seg * (n_ring - 1)."""
+    th = np.arange(1, n_ring)[:, None] * (np.pi / n_ring)
+    ph = np.arange(n_seg)[None, :] * (2 * np.pi / n_seg)
+    r = 1.0 + modulate * np.sin(3 * th) * np.cos(2 * ph)
+    body = np.stack([r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), r * np.cos(th) + 0 * ph], -1).reshape(-1, 3)
+    vs = np.concatenate([[[0.0, 0.0, 1.0]], body, [[0.0, 0.0, -1.0]]])
+    north, south = 0, len(vs) - 1
+    idx = lambda i, j: 1 + i * n_seg + (j % n_seg)
+    faces = []
+    j = np.arange(n_seg)
+    faces.append(np.stack([np.full(n_seg, north), idx(0, j), idx(0, j + 1)], 1))
+    for i in range(n_ring - 2):
+        a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+        faces.append(np.stack([a, b, c], 1))
+        faces.append(np.stack([a, c, d], 1))
+    faces.append(np.stack([np.full(n_seg, south), idx(n_ring - 2, j + 1), idx(n_ring - 2, j)], 1))
+    return vs, np.concatenate(faces).astype(np.int64)
+
+
+def valence_histogram(faces, nv):
+    """-> counts[k] = vertices of valence k (closed manifold: valence = incident faces)."""
+    return np.bincount(np.bincount(np.asarray(faces).reshape(-1), minlength=nv))

@@ -13,6 +13,8 @@ ap.add_argument("--rows", type=int, default=1000000)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--order", default="native")
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+ap.add_argument("--flip", type=int, default=0, help="rounds of random edge flips (irregular valence)")
+ap.add_argument("--widths", default="512,256,128,64,32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = a.rows
@@ -48,7 +50,12 @@ if a.what in ("spmm", "all"):
     # face graph of a torus with n faces (deg 3+1) and vertex graph with n/2 verts (deg 6+1)
     nv_ = int(round((n / 4.0) ** 0.5)); nu_ = n // (2 * nv_)
     v, f = synth.torus(nu_, nv_)
-    if a.order == "random":
+    if a.flip:
+        f = synth.flip_edges(v, f, rounds=a.flip, seed=1)
+        f = synth.add_hub(v, f, 1234, 24)
+    if a.order == "rcb":
+        v, f = synth.rcb_relabel(v, f)
+    elif a.order == "random":
         v, f = synth.permute_vertices(v, f, 0); f = synth.permute_faces(f, 0)
     elif a.order == "morton":
         v, f = synth.morton_relabel(v, f)
@@ -57,15 +64,17 @@ if a.what in ("spmm", "all"):
     fi = torch.from_numpy(m.f_edges).to(dev)
     for gname, idx, nn_ in (("face", fi, len(f)), ("vert", ei, len(v))):
         g = ops.graph_for(idx, nn_)
-        for C in (512, 256, 128, 64, 32):
+        for C in [int(c) for c in a.widths.split(",")]:
             X = torch.randn(nn_, C, device=dev).to(DT); Y = torch.empty(nn_, C, device=dev, dtype=DT)
             us = timeit(lambda: ops.spmm(g, X, out=Y))
             alg = 2.0 * nn_ * C * ES + 4.0 * g.nnz + 8.0 * nn_
             print("spmm %s N=%d C=%3d  %8.0f us  %7.1f GB/s alg (%.1f%% of 8 TB/s)  gather-logical %.1f GB/s" % (
                 gname, nn_, C, us, alg / us / 1e3, alg / us / 1e3 / 80.0, (g.nnz * C * 4.0 + nn_ * C * 4.0) / us / 1e3))
-            if C >= 128:
+            if C >= 32:
                 sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev)
                 us_p = timeit(lambda: ops.spmm(g, X, out=Y, pro=(sc, sh)))
+                sums0 = torch.empty(2 * C, dtype=torch.float64, device=dev); ref0 = torch.zeros(C, device=dev)
+                us_t = timeit(lambda: ops.spmm_stats(g, X, Y, ref0, sums0, bias=sh))
                 bn4 = torch.rand(4, C, device=dev) + 0.5; sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
                 Yp = torch.randn(nn_, C, device=dev).to(DT)
                 us_r = timeit(lambda: ops.spmm_bnred(g, X, Y, Yp, bn4, sums))
@@ -74,6 +83,7 @@ if a.what in ("spmm", "all"):
                 dY = torch.empty_like(X)
                 us_a = timeit(lambda: ops.bn_bwd_apply(X, Yp, bn4, c10, dY, sums))
                 us_s = timeit(lambda: ops.bn_bwd_reduce(X, Yp, bn4, sums2=sums))
+                print("     +statistics %8.0f us (x%.2f)" % (us_t, us_t / us))
                 print("     +prologue %8.0f us (x%.2f)   +bn-backward reduce %8.0f us (x%.2f; separate pass %.0f us)   "
                       "bn-backward on the gather %8.0f us (apply pass %.0f us + plain)" % (us_p, us_p / us, us_r, us_r / us, us_s, us_b, us_a))
 

@@ -95,8 +95,8 @@ def test_batchnorm_normalises_at_1m():
 
 
 def test_training_iteration_invariances_at_1m(big):
-    """Same first iteration (a) with and without the internal Morton relabelling, (b) on 2 logical ranks with
-    halo exchange; also: finite, decreasing loss over three iterations."""
+    """Same first iteration (a) with the internal RCB relabelling (the default), the Morton one and none, (b) on 2 logical
+    ranks with halo exchange; also: finite, decreasing loss over three iterations."""
     from dual_dmp_amd import dist as D
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
@@ -110,15 +110,16 @@ def test_training_iteration_invariances_at_1m(big):
         out = [(tr.step().item(), tr.pos.clone(), tr.norm.clone()) for _ in range(steps)]
         return out
 
-    base = run("morton", 3)
+    base = run("rcb", 3)
     losses = [b[0] for b in base]
     assert all(np.isfinite(losses)) and losses[2] < losses[0], losses
-    plain = run(None, 1)
-    assert abs(plain[0][0] - base[0][0]) <= 1e-6 * abs(base[0][0])
-    assert float((plain[0][1] - base[0][1]).abs().max()) < 5e-5
-    assert float((plain[0][2] - base[0][2]).abs().max()) < 5e-5
-    del plain
-    torch.cuda.empty_cache()
+    for other in (None, "morton"):
+        plain = run(other, 1)
+        assert abs(plain[0][0] - base[0][0]) <= 1e-6 * abs(base[0][0]), other
+        assert float((plain[0][1] - base[0][1]).abs().max()) < 5e-5, other
+        assert float((plain[0][2] - base[0][2]).abs().max()) < 5e-5, other
+        del plain
+        torch.cuda.empty_cache()
 
     P = 2
     nets = []
