@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+GUIDE_COPY_GBS = 6290.0        # MI355X_MICROARCH.md: "6.29 TB/s measured (float4 copy, 79%)"
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
@@ -59,8 +60,11 @@ def parse_args(argv=None):
     ap.add_argument("--bf16-extra", type=int, default=1,
                     help="1: the default f32 run also measures the bf16-feature mode (BASELINE configs[1] arithmetic) on the same "
                          "mesh after the f32 timed region and reports it as the \"bf16\" object of the JSON line")
-    ap.add_argument("--cpu-iters", type=int, default=1,
-                    help="timed oracle iterations of the CPU baseline after its one warm-up (~70 s each at 1M faces)")
+    ap.add_argument("--cpu-iters", type=int, default=2,
+                    help="timed oracle iterations of the CPU baseline after its one warm-up (~70 s each at 1M faces; a warm-up "
+                         "slower than 150 s cuts them to 1)")
+    ap.add_argument("--irregular", type=int, default=1,
+                    help="1: also time the step on the same mesh after random edge flips (irregular valence), outside the timed region")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--extras", type=int, default=1,
                     help="1: also measure (outside the timed region) gate-open iterations, a randomly numbered mesh and the eval block")
@@ -106,11 +110,16 @@ def torus_dims(faces):
     return nu, nv
 
 
-def build_case(faces, order):
+def build_case(faces, order, irregular=False):
+    """irregular: ten rounds of random manifold-preserving edge flips (valence 3 ... 12+ instead of 6 everywhere) and one
+    valence-24 hub on the same vertex set (synth.flip_edges / add_hub): what a scan or a decimated model looks like."""
     from dual_dmp_amd import synth
     from dual_dmp_amd.datamaker import dataset_from_meshes
     nu, nv = torus_dims(faces)
     v, f = synth.torus(nu, nv)
+    if irregular:
+        f = synth.flip_edges(v, f, rounds=10, seed=1)
+        f = synth.add_hub(v, f, len(v) // 3, 24)
     if order == "random":
         v, f = synth.permute_vertices(v, f, 0)
         f = synth.permute_faces(f, 0)
@@ -203,17 +212,20 @@ def cpu_baseline(sample_faces, target_faces, iters=3, f64_truth=False):
     first = step(1)                                    # warm-up (allocator, index caches); also the parity reference
     warm = time.perf_counter() - t0
     iters = iters if warm <= 80.0 else min(iters, 2) if warm <= 150.0 else 1
-    later = []
+    later, each = [], []
     t0 = time.perf_counter()
     for ep in range(2, 2 + iters):
+        t1 = time.perf_counter()
         later.append(step(ep)[0])
+        each.append(time.perf_counter() - t1)
     dt = (time.perf_counter() - t0) / iters
     rss_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     extra = "" if F == target_faces else "; value = linear extrapolation to %d faces (host memory %.0f GB < 128 GB)" % (target_faces, mem)
     return {
         "_ref": {"faces": F, "loss": [first[0]] + later, "pos": first[1], "norm": first[2],
                  "pos64": None if truth is None else truth[0], "norm64": None if truth is None else truth[1], "f64_forward_s": t64},
-        "value": (1.0 / dt) * F / target_faces, "unit": "iters/s", "cores": best, "kind": "port",
+        "value": (1.0 / dt) * F / target_faces, "unit": "iters/s", "cores": best, "threads": best, "host_cores": ncpu, "kind": "port",
+        "timed_iters": iters, "s_per_iter_each": [round(x, 2) for x in each],
         "sample": "oracle train_step (PyTorch CPU, PyG-shaped index_select*w+index_add per layer, gcn_norm per call), %d faces / "
                   "%d verts, %d threads (calibrated: 20k-face probe %s s/iter, at 100k faces %s s/iter; %d-core host, %.0f GB), "
                   "1 warm-up (%.1f s) + %d timed iters: %.2f s/iter = %.5f iters/s at that size, peak RSS %.1f GB%s"
@@ -350,8 +362,13 @@ def gather_ceilings(dev, sizes, dtype, copy_gbs=None):
         us = sorted(times)[len(times) // 2]
         alg = 2.0 * n * C * X.element_size() + 4.0 * g.nnz + 8.0 * n
         gbs = alg / us / 1e3
-        if copy_gbs is None or gbs >= 0.5 * copy_gbs:     # a figure below half the device-copy rate is a measurement accident
-            out[int(round(g.nnz / n))] = round(gbs, 1)   # (the driver's round-3 box returned 859 GB/s once): not reported
+        # (a figure below half the device-copy rate is a measurement accident -- the driver's round-3 box returned 859 GB/s once --:
+        #  kept and FLAGGED, not used as a ceiling)
+        key = int(round(g.nnz / n))
+        if copy_gbs is None or gbs >= 0.5 * copy_gbs:
+            out[key] = round(gbs, 1)
+        else:
+            out.setdefault("_discarded", {})[str(key)] = round(gbs, 1)
         del g, X, Y
     torch.cuda.empty_cache()
     return out
@@ -444,12 +461,23 @@ def parity_object(hip, ref):
     out["later_iterations_rel"] = [abs(hip["loss"][i] - ref["loss"][i]) / abs(ref["loss"][i]) for i in range(1, n)]
     out["later_iterations_note"] = ("free-running iterations 2.. (graph capture, then replay): informational -- chaotic under Adam, "
                                     "the oracle's own float32 / float64 runs separate ~10x per iteration")
-    out["bounds"] = {"rel": 1e-5, "max_abs_dpos": 1e-3, "max_abs_dnorm": 1e-3, "mad_delta_deg": 1e-3}
-    # (normals: the maximum within the bound, or -- short un-normalised vectors, see above -- all but <= 1e-5 of the faces, or, when
-    #  the float64 truth was computed, the HIP path no further from it than twice the float32 reference itself)
-    norm_ok = (out["max_abs_dnorm"] <= 1e-3 or (out["dnorm_p9999"] <= 2e-4 and out["dnorm_rows_above_1e-3"] <= 1e-5 * hip["faces"])
-               or bool(noise_ok))
-    out["ok"] = bool(out["rel"] <= 1e-5 and out["max_abs_dpos"] <= 1e-3 and norm_ok and out["mad_delta_deg"] <= 1e-3)
+    # The normals' clause, in the order tried; "normals_ok_by" names the one that decided:
+    #   max      max|dnorm| <= 1e-3 (SURVEY.md 8d's bound as written)
+    #   quantile all but <= 1e-5 of the faces within 1e-3 and the 99.99 % quantile <= 2e-4 (NormalNet's head divides by the length
+    #            of its tanh output: a short vector amplifies the float32 noise of BOTH sides; the oracle's threaded CPU run is not
+    #            bit-reproducible and its maximum over 1M faces moves 2.5e-4 ... 4e-3 between runs)
+    #   f64      the HIP normals are no further from the oracle's FLOAT64 forward than twice the oracle's own float32 run is
+    #            (rms and 99.99 % quantile; positions rms likewise)
+    by = ("max" if out["max_abs_dnorm"] <= 1e-3 else
+          "quantile" if (out["dnorm_p9999"] <= 2e-4 and out["dnorm_rows_above_1e-3"] <= 1e-5 * hip["faces"]) else
+          "f64" if noise_ok else None)
+    out["normals_ok_by"] = by
+    out["bounds"] = {"rel": 1e-5, "max_abs_dpos": 1e-3, "mad_delta_deg": 1e-3,
+                     "normals": {"max": "max_abs_dnorm <= 1e-3",
+                                 "quantile": "dnorm_p9999 <= 2e-4 and dnorm_rows_above_1e-3 <= 1e-5 * faces",
+                                 "f64": "vs_float64.hip within 2x of vs_float64.oracle_float32 (dnorm rms, p9999; dpos rms)",
+                                 "decided_by": by}}
+    out["ok"] = bool(out["rel"] <= 1e-5 and out["max_abs_dpos"] <= 1e-3 and by is not None and out["mad_delta_deg"] <= 1e-3)
     return out
 
 
@@ -720,25 +748,65 @@ def main():
         del tr2
         torch.cuda.empty_cache()
 
-    # ---- what a plain device copy (half read, half write: the traffic shape of a gather or a row-panel GEMM) reaches on THIS
-    # box: context for the fractions of the 8 TB/s peak above (outside the timed region)
+    # ---- the same step on an IRREGULAR mesh (round 5): the same vertices after ten rounds of random edge flips + a valence-24 hub
+    # (vertex graph rows of 4 ... 25 entries instead of 7 everywhere; what scans and non-CAD models look like), with its own
+    # profiled pass for the gather's roofline.  Outside the timed region.
+    if args.irregular and args.extras and not multi and args.order == "native":
+        tr = None
+        torch.cuda.empty_cache()
+        t_i = time.perf_counter()
+        gt3, noisy3, smooth3, data3 = build_case(args.faces, "native", irregular=True)
+        hist = np.bincount(np.bincount(noisy3.faces.reshape(-1), minlength=len(noisy3.vs)))
+        tr3 = make_trainer(noisy3, smooth3, data3)
+        setup_i = time.perf_counter() - t_i
+        for _ in range(3):
+            tr3.step().item()
+        ms_i = timed_steps(tr3, max(5, args.steps // 2), sync)[0]
+        irr = {"ms_per_step": round(ms_i, 3), "vs_regular": round(ms_i / ms_per_step, 4), "setup_s": round(setup_i, 1),
+               "valence_histogram": {str(k): int(c) for k, c in enumerate(hist) if c},
+               "what": "the bench mesh after synth.flip_edges(rounds=10) + add_hub(valence 24): same V / F, same step"}
+        if args.profile_steps > 0:
+            oi = {}
+            _, rgi, _ = profiled_pass(tr3, args.dtype, oi)
+            if isinstance(rgi, dict):
+                rgi.pop("_by_fan_in", None)
+                rgi["traffic"], rgi["traffic_source"] = None, "not profiled on this mesh"
+            irr.update({"roofline_gather": rgi, "kernel_ms_per_step": oi.get("kernel_ms_per_step")})
+        out["irregular_ms_per_step"] = irr["ms_per_step"]
+        out["irregular"] = irr
+        del tr3, gt3, noisy3, smooth3, data3
+        torch.cuda.empty_cache()
+
+    # ---- what a device copy (half read, half write: the traffic shape of a gather or a row-panel GEMM) reaches on THIS box:
+    # context for the fractions of the 8 TB/s peak above (outside the timed region).  The yardstick is the library's OWN
+    # streaming copy (ddmp_copy_probe: 16 bytes per lane, XCD-contiguous, plain and nontemporal -- the better of the two), next to
+    # the guide's 6.29 TB/s float4 copy; torch's copy_ (which round 4 divided by: 4.7-5.1 TB/s) is reported beside it.
     if rank == 0:
         src = torch.empty(512 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()        # 2 GiB read + 2 GiB written
         dst = torch.empty_like(src)
-        dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+        def copy_rate(fn):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        torch_copy_gbs = copy_rate(lambda: dst.copy_(src))
+        probe = {"plain": copy_rate(lambda: ops.copy_probe(src, dst, 0)), "nontemporal": copy_rate(lambda: ops.copy_probe(src, dst, 1))}
+        copy_gbs = max(probe.values())
+        out["device_copy"] = {"ddmp_copy_probe_GBs": {k: round(v, 1) for k, v in probe.items()}, "torch_copy__GBs": round(torch_copy_gbs, 1),
+                              "guide_float4_copy_GBs": GUIDE_COPY_GBS,
+                              "what": "2 GiB read + 2 GiB written; frac_of_device_copy below divides by the better ddmp_copy_probe figure"}
         del src, dst
         torch.cuda.empty_cache()
         for r_ in (roof, roof_gather) + ((bf16.get("roofline"), bf16.get("roofline_gather")) if bf16 else ()):
             if isinstance(r_, dict) and r_.get("bound") == "hbm":
                 r_["device_copy_GBs"] = round(copy_gbs, 1)
                 r_["frac_of_device_copy"] = round(r_["achieved"] / copy_gbs, 4)
+                r_["frac_of_guide_copy_6290"] = round(r_["achieved"] / GUIDE_COPY_GBS, 4)
         # the gather's on-chip ceiling per fan-in, measured now (see gather_ceilings), and the fraction of it the step's launches reach
         for r_, dt_ in ((roof_gather, fdt),) + (((bf16.get("roofline_gather"), torch.bfloat16),) if bf16 else ()):
             if not (isinstance(r_, dict) and r_.get("_by_fan_in")):
@@ -746,6 +814,7 @@ def main():
             fan = r_.pop("_by_fan_in")
             sizes = {e: (F if e <= 5 else V) for e in fan}
             ceil = gather_ceilings(dev, sizes, dt_, copy_gbs)
+            discarded = ceil.pop("_discarded", None)
             t_floor = sum(v["bytes"] / (ceil[e] * 1e9) for e, v in fan.items() if e in ceil) * 1e3      # ms
             r_["by_fan_in"] = {str(e): {"ms_per_step": round(v["ms"], 3), "achieved_GBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
                                         "frac": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -753,6 +822,7 @@ def main():
             r_["ceiling"] = {"what": "the same kernel on perfectly local ring graphs with the same CSR entries per row (4 = face "
                                      "graph, 7 = vertex graph), C = 512, measured in this run: no numbering of a mesh can beat it",
                              "GBs_by_entries_per_row": {str(k): v for k, v in ceil.items()},
+                             "discarded_below_half_the_copy_rate": discarded,
                              "ms_per_step_at_ceiling": round(t_floor, 3),
                              "frac_of_ceiling": (round(t_floor / r_["ms_per_step"], 4)
                                                  if r_["ms_per_step"] and all(e in ceil for e in fan) else None)}

@@ -69,6 +69,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Position of this lane's row when the 64 rows of a chunk (lane = row) are ordered by DESCENDING key (stable; key in
+// -1 .. 31, -1 = "not a row": last).  The gather kernels process 8 rows per wave step in lockstep, so rows of similar length
+// belong in the same step (irregular meshes: a step of 8 rows costs its LONGEST row; sorted, the long rows share a few steps).
+// All keys equal (regular meshes): the identity, at the price of two wave reductions.
+__device__ __forceinline__ int chunk_rank_desc(int key, int lane) {
+    int kmax = key, kmin = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmax = max(kmax, __shfl_xor(kmax, o, 64));
+        kmin = min(kmin, __shfl_xor(kmin, o, 64));
+    }
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    kmin = __builtin_amdgcn_readfirstlane(kmin);
+    if (kmax == kmin) return lane;
+    int rank = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int v = kmax; v >= kmin; --v) {                         // (uniform: at most 33 rounds)
+        const unsigned long long m = __ballot(key == v);
+        if (key < v) rank += __popcll(m);
+        else if (key == v) rank += __popcll(m & below);
+    }
+    return rank;
+}
+
 // block-level sum of one double per thread; result valid in thread 0. `sm` holds >= blockDim/64 doubles.
 __device__ __forceinline__ double block_sum(double v, double* sm) {
     v = wave_sum(v);

@@ -35,6 +35,59 @@ extern "C" int ddmp_trace_marker(ddmp_stream stream) {
     return DDMP_OK;
 }
 
+// The yardstick of bench.py's "fraction of what a copy reaches" figures: a streaming copy written like the kernels it is
+// compared with (16 bytes per lane, 4 loads in flight per lane before the first store, workgroup b on XCD b % 8 walking
+// that XCD's contiguous eighth of the buffer) -- NOT torch's elementwise copy_ (4.7-5.1 TB/s on these boxes, which flattered
+// every "x % of a device copy" in round 4; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).  mode 0: plain loads and
+// stores; 1: nontemporal loads and stores (what the gather's output stores use).
+template <int MODE>
+__global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                         int blocks_per_xcd) {
+    typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+    const int64_t per_xcd = (n16 + ddmp::kXcd - 1) / ddmp::kXcd;
+    const int64_t lo = (int64_t)(blockIdx.x & (ddmp::kXcd - 1)) * per_xcd, hi = min(n16, lo + per_xcd);
+    const int64_t step = (int64_t)blocks_per_xcd * 1024;
+    for (int64_t i = lo + (int64_t)(blockIdx.x >> 3) * 1024 + threadIdx.x; i < hi; i += step) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = min(i + 256 * u, hi - 1);
+            if (MODE == 1) {
+                const nt_u4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(src + j));
+                v[u] = make_uint4(t.x, t.y, t.z, t.w);
+            } else {
+                v[u] = src[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + 256 * u;
+            if (j < hi) {
+                if (MODE == 1) {
+                    nt_u4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt_u4*>(dst + j));
+                } else {
+                    dst[j] = v[u];
+                }
+            }
+        }
+    }
+}
+extern "C" int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_stream stream) {
+    ARG_TRY(src && dst && bytes > 0 && bytes % 16 == 0 && (mode == 0 || mode == 1));
+    ARG_TRY(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
+    const int bpx = 256;                                         // 2048 workgroups: 8 per CU
+    const int64_t n16 = bytes / 16;
+    if (mode == 1)
+        hipLaunchKernelGGL(copy_probe_kernel<1>, dim3(bpx * ddmp::kXcd), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                           (uint4*)dst, n16, bpx);
+    else
+        hipLaunchKernelGGL(copy_probe_kernel<0>, dim3(bpx * ddmp::kXcd), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                           (uint4*)dst, n16, bpx);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
 // ---------------------------------------------------------------- tail-fused finalisation of column reductions (finalize.h)
 namespace ddmp {
 static thread_local FinalizeArgs g_fin_pending, g_fin_active;

@@ -584,8 +584,17 @@ extern "C" int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t 
         return ddmp_bn_stats_f32(Y, ldy, g->n_rows, C, sums2, ws, ws_bytes, stream);
     }
     BnRed red{nullptr, 0, nullptr, nullptr, ref, nullptr, (float*)ws};
-    const int rc = pro_scale ? launch_lean<true, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red)
-                             : launch_lean<false, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
+    // LDS-patch kernel where selected (one record per chunk, like the lean gather; its heavy chunks: the lean gather's list)
+    int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr, nullptr, ref,
+                              nullptr, (float*)ws, st);
+    const bool patched = rc == DDMP_OK;
+    if (rc != DDMP_OK && rc != ddmp::kPatchNotApplicable) return rc;
+    const int* list = patched ? g->heavy : nullptr;
+    if (!patched || g->n_heavy > 0)
+        rc = pro_scale ? launch_lean<true, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red, BnBwdGather(),
+                                                     list, g->n_heavy)
+                       : launch_lean<false, 2, false>(lp, g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red, BnBwdGather(),
+                                                      list, g->n_heavy);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)lp.n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, lp.n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
     constexpr int RPB = 4 * RPW;
     __shared__ int s_rowptr[kRB + 1];
     __shared__ int s_slot[kRB];                                  // LEAN: (first quad of the row's slots) * 512 + its quad count
+    __shared__ int s_perm[kRB];                                  // the chunk's rows, longest first (LEAN; else the identity)
     __shared__ __attribute__((aligned(16))) uint2 s_ent[kMaxE];  // LEAN: (offset, weight) slots; else: s_col | s_w
     int* s_col = reinterpret_cast<int*>(s_ent);
     float* s_w = reinterpret_cast<float*>(s_ent) + kMaxE;
@@ -138,6 +139,8 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         }
         const int qoff_l = incl - nq_l;
         staged = __shfl(incl, 63, 64) * 4 <= kMaxE;              // (the same in every wave)
+        const int rank_l = chunk_rank_desc(ln < nr ? min(nq_l, 31) : -1, ln);
+        if (tid < 64) s_perm[rank_l] = ln;
         if (tid < nr) s_slot[tid] = staged ? qoff_l * 512 + nq_l : 0;
         if (staged) {
             const int lr = tid >> 2;
@@ -148,12 +151,14 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 s_ent[4 * qo + k] = make_uint2((unsigned)c * ld16, k < nn ? __float_as_uint(dinv[c]) : 0u);
             }
         }
-    } else if (staged) {
-        for (int t = tid; t < ne; t += 256) {
-            const int c = col[e0 + t];
-            s_col[t] = c;
-            s_w[t] = dinv[c];
-        }
+    } else {
+        if (tid < 64) s_perm[tid] = tid;
+        if (staged)
+            for (int t = tid; t < ne; t += 256) {
+                const int c = col[e0 + t];
+                s_col[t] = c;
+                s_w[t] = dinv[c];
+            }
     }
     __syncthreads();
 
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         }
         const bf16_t* xc = X + off;
         const bf16_t* yc = BWD ? bwd.Yb + off : nullptr;
-        for (int lr = wave * RPW + grp; lr < nr; lr += RPB) {
+        for (int pos = wave * RPW + grp; pos < nr; pos += RPB) {
+            const int lr = s_perm[pos];
             const int sq = SLOTS ? s_slot[lr] : 0;
             int es = SLOTS ? 0 : s_rowptr[lr] - e0;
             const int ee = SLOTS ? 4 * (sq & 511) : s_rowptr[lr + 1] - e0;
@@ -461,8 +467,16 @@ extern "C" int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int6
     }
     const int n_chunks = (int)cdiv(g->n_rows, kRB);
     BnRedB red{nullptr, 0, nullptr, nullptr, ref, nullptr, (float*)ws};
-    const int rc = pro_scale ? dispatch_b16<true, 2, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red)
-                             : dispatch_b16<false, 2, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red);
+    int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr, nullptr, ref,
+                              nullptr, (float*)ws, st);
+    const bool patched = rc == DDMP_OK;
+    if (rc != DDMP_OK && rc != ddmp::kPatchNotApplicable) return rc;
+    const int* list = patched ? g->heavy : nullptr;
+    if (!patched || g->n_heavy > 0)
+        rc = pro_scale ? dispatch_b16<true, 2, false>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st, red, BnBwdGatherB(),
+                                                      list, g->n_heavy)
+                       : dispatch_b16<false, 2, false>(g, X, ldx, Y, ldy, C, bias, nullptr, nullptr, slope, st, red, BnBwdGatherB(),
+                                                       list, g->n_heavy);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
     fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);    // (one record per chunk)

@@ -72,7 +72,9 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 // meshes: valence 3 ... 12+) continue from the LDS lists -- the same sums in the same order --, behind a wave-uniform test that
 // a wave of short rows never enters; chunks the kernel cannot take at all (ddmp_graph: "heavy") return at once and are
 // computed by the lean gather.  Rows without entries (csr_host graphs) are legal: weight 0 on patch row 0.
-template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
+// RED: 0 | 1 the BatchNorm-backward reductions of the output (RedArgs; the chunk's own Yp rows ride the DMA ring) | 2 (round 5)
+// the BatchNorm STATISTICS of the output around the per-column reference red.mean (see spmm_lean.inc): sum (y - ref), (y - ref)^2
+template <typename T, int KD, bool PRO, int RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
     const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
@@ -81,10 +83,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     int chunks_per_xcd, int n_chunks, RedArgs red) {
     constexpr int VW = Lane<T>::VW, CS = 8 * VW;                 // channels per 128-byte slab
     constexpr int PR = 32 * KD;                                  // patch rows per buffer
-    constexpr int KR = RED ? 2 : 0;                              // copies per wave and slab of the chunk's own Yp rows
+    constexpr int KR = RED == 1 ? 2 : 0;                         // copies per wave and slab of the chunk's own Yp rows
     constexpr int NST = 2;                                       // output stores per lane and slab
     constexpr int NSR = RED ? 1 : 0;                             // + the wave's quarter of the previous slab's partial record
-    constexpr int kBuf = PR * 128 + (RED ? kRB * 128 : 0);       // bytes per buffer
+    constexpr int kBuf = PR * 128 + (RED == 1 ? kRB * 128 : 0);  // bytes per buffer
     constexpr int kNB = NB;
     constexpr int NWAIT = (KD + KR) * (kNB - 2) + (NST + NSR) * (kNB - 1);   // VMEM operations younger than the copies of slab s
     static_assert(NWAIT <= 63, "vmcnt range");
@@ -96,9 +98,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     int* s_rowptr = reinterpret_cast<int*>(s_dinv + kRB);        // [kRB + 1] (+3 pad)
     int* s_pl = s_rowptr + kRB + 4;                              // [PR]
     unsigned short* s_lc = reinterpret_cast<unsigned short*>(s_pl + PR);      // [kMaxE]
-    float* s_coef = reinterpret_cast<float*>(s_lc + kMaxE);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd
+    int* s_perm = reinterpret_cast<int*>(s_lc + kMaxE);          // [kRB]: the chunk's rows, longest first (chunk_rank_desc)
+    float* s_coef = reinterpret_cast<float*>(s_perm + kRB);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd (RED 2: ref)
     // RED: the four waves' partial sums of a slab, by slab parity: [2][4 waves][2 sums][CS]
-    float* s_part = s_coef + (RED ? 7 : PRO ? 3 : 1) * C;
+    float* s_part = s_coef + (RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C;
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -120,14 +123,19 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             s_coef[C + i] = pscale[i];
             s_coef[2 * C + i] = pshift[i];
         }
-        if (RED) {
+        if (RED == 1) {
             s_coef[3 * C + i] = red.scale[i];
             s_coef[4 * C + i] = red.shift[i];
             s_coef[5 * C + i] = red.mean[i];
             s_coef[6 * C + i] = red.rstd[i];
         }
+        if (RED == 2) s_coef[3 * C + i] = red.mean[i];
     }
     __syncthreads();
+    if (wave == 0) {                                             // rows of similar length share a wave (see chunk_rank_desc)
+        const int nn_l = lane < nr ? s_rowptr[lane + 1] - s_rowptr[lane] : -4;
+        s_perm[chunk_rank_desc(min((nn_l + 3) >> 2, 31), lane)] = lane;
+    }
     const int e0 = s_rowptr[0];
     const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (dispatcher: max_row_nnz <= 16)
     for (int t = tid; t < ne; t += 256) {
@@ -135,6 +143,9 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         s_w[t] = dinv[col[e0 + t]];
     }
     __syncthreads();                                             // (plain loads above: all waited for by now)
+    int rows[2];                                                 // this lane's two rows (local indices; clamped on a ragged chunk)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rows[q] = s_perm[min(wave * 16 + grp + 8 * q, nr - 1)];
 
     // NE > 0: this lane's rows (wave * 8 + grp, + 32) -- byte offset of the entry's patch row (+ the lane's 16 bytes) and weight;
     // a row's missing entries repeat its last one with weight 0 (no further distinct LDS row, the sum unchanged)
@@ -146,10 +157,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     if (NE > 0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int lr = wave * 8 + grp + 32 * q;
-            const int lrc = min(lr, nr - 1);
+            const int pos = wave * 16 + grp + 8 * q;             // (positions 16 w .. 16 w + 15 of the ordered rows: wave w)
+            const int lrc = s_perm[min(pos, nr - 1)];
             const int es = s_rowptr[lrc] - e0;
-            const int nn = lr < nr ? s_rowptr[lrc + 1] - s_rowptr[lrc] : 0;
+            const int nn = pos < nr ? s_rowptr[lrc + 1] - s_rowptr[lrc] : 0;
             nmax = max(nmax, nn);
             tail_es[q] = es + min(nn, NEc);
             tail_ee[q] = es + nn;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
 
     const int n_slabs = C / CS;
     const T* xlane = X + sl * VW;
-    const T* yplane = RED ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
+    const T* yplane = RED == 1 ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
     // copies of slab s into buffer b: wave w, instruction i covers patch rows (4 i + w) * 8 .. + 7
     auto copy = [&](int s, unsigned char* dst) {
 #pragma unroll
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             const int row = s_pl[j0 + grp];
             dma16(xlane + (int64_t)row * ldx + s * CS, dst + j0 * 128);
         }
-        if (RED) {
+        if (RED == 1) {
 #pragma unroll
             for (int i = 0; i < KR; ++i) {
                 const int j0 = (4 * i + wave) * 8;                // own rows j0 .. j0 + 7 of the chunk
@@ -236,9 +247,9 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         for (int j = 0; j < VW; ++j) q0[j] = q1[j] = 0.f;
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
-            const int lr = wave * 8 + grp + 32 * q;
-            const bool on = lr < nr;
-            const int lrc = min(lr, nr - 1);
+            const int pos = wave * 16 + grp + 8 * q;
+            const bool on = pos < nr;
+            const int lrc = rows[q], lr = lrc;
             int es = NE > 0 ? 0 : s_rowptr[lrc] - e0;
             const int ee = NE > 0 ? tail_ee[q] : (on ? s_rowptr[lrc + 1] - e0 : es);
             float acc[VW];
@@ -299,7 +310,16 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                 nt_u4 ov = {ob.x, ob.y, ob.z, ob.w};
                 __builtin_nontemporal_store(ov, reinterpret_cast<nt_u4*>(Y + (int64_t)(r0 + lr) * ldy + off));
             }
-            if (RED && on) {                                     // on the values as stored
+            if (RED == 2 && on) {                                // statistics of the values as stored, around the reference
+                Lane<T>::unpack(ob, o);
+#pragma unroll
+                for (int j = 0; j < VW; ++j) {
+                    const float d = o[j] - s_coef[3 * C + off + j];
+                    q0[j] += d;
+                    q1[j] = fmaf(d, d, q1[j]);
+                }
+            }
+            if (RED == 1 && on) {                                // on the values as stored
                 float y[VW];
                 Lane<T>::unpack(ob, o);
                 Lane<T>::unpack(*reinterpret_cast<const uint4*>(pb + PR * 128 + lr * 128), y);
@@ -355,16 +375,16 @@ int patch_nb() {                                                  // DDMP_SPMM_P
     return nb;
 }
 
-template <typename T, int KD, bool PRO, bool RED, int NB>
+template <typename T, int KD, bool PRO, int RED, int NB>
 size_t patch2_lds(int C) {
     const int PR = 32 * KD;
-    const size_t buf = (size_t)PR * 128 + (RED ? kRB * 128 : 0);
+    const size_t buf = (size_t)PR * 128 + (RED == 1 ? kRB * 128 : 0);
     const size_t cs = 128 / sizeof(T);
-    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + (size_t)(RED ? 7 : PRO ? 3 : 1) * C * 4 +
-           (RED ? 2 * 4 * 2 * cs * 4 : 0);
+    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + kRB * 4 +
+           (size_t)(RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C * 4 + (RED ? 2 * 4 * 2 * cs * 4 : 0);
 }
 
-template <typename T, int KD, bool PRO, bool RED, int NB, int NE>
+template <typename T, int KD, bool PRO, int RED, int NB, int NE>
 int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                     const float* psh, float slope, hipStream_t st, RedArgs red) {
     const int n = (int)g->n_rows;
@@ -396,7 +416,7 @@ int patch_ne() {                                                  // DDMP_SPMM_P
     return v;
 }
 
-template <typename T, int KD, bool PRO, bool RED>
+template <typename T, int KD, bool PRO, int RED>
 int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                   const float* psh, float slope, hipStream_t st, RedArgs red) {
     // (the A/B buffer counts keep the LDS-entry form)
@@ -410,7 +430,7 @@ int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ld
     return launch_patch2nb<T, KD, PRO, RED, 2, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
-template <typename T, bool PRO, bool RED>
+template <typename T, bool PRO, int RED>
 int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
              const float* psh, float slope, hipStream_t st, RedArgs red) {
     switch (g->patch_kd) {                                       // (chosen per graph: ddmp_graph, graph.hip)
@@ -447,37 +467,59 @@ int patch_mode() {
 
 }  // namespace
 
+// DDMP_SPMM_PATCH_FORMS (A/B, default 7): bit 0 the prologue form at C >= 512, bit 1 the fused BatchNorm-backward reduction at
+// C >= 512, bit 2 the fused statistics form (C >= 256) on the LDS-patch kernel -- round 5, measured with the RCB numbering (smaller
+// patches: KD = 5 instead of 6, one more workgroup per CU), 1M faces, us per launch patch | lean (profiles/r05_gather_forms.txt):
+//   prologue C = 512 face 819 | 935, vertex 514 | 627;  reduction C = 512 face 1261 | 1284, vertex 711 | 747 (C = 256: a tie)
+int patch_forms() {
+    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_FORMS"); return e ? atoi(e) : 7; }();
+    return v;
+}
+
 // does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
+// has_red: 0 | 1 the BatchNorm-backward reductions | 2 the statistics form
 extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red) {
     if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || !g->lcol) return 0;
-    // (measured selection, see by_patch's note: float32, no fused reduction, plain C >= 256, prologue 256 <= C < 512; row lengths
-    //  are not a condition since round 5 -- DDMP_SPMM_PATCH_MAXNNZ=n keeps the A/B switch "graphs with longer rows stay lean")
-    if (patch_mode() == 3 && (dtype != DDMP_F32 || has_red || g->max_row_nnz > patch_max_nnz() || C < 256 || (has_pro && C >= 512))) return 0;
+    if (has_red == 1 && has_pro) return 0;                       // (no such form)
+    if (patch_mode() == 3) {
+        // measured selection (by_patch's note, patch_forms): float32, C >= 256; row lengths are not a condition since round 5
+        // (DDMP_SPMM_PATCH_MAXNNZ=n keeps the A/B switch "graphs with longer rows stay lean")
+        if (dtype != DDMP_F32 || g->max_row_nnz > patch_max_nnz() || C < 256) return 0;
+        if (has_red == 1 && !((patch_forms() & 2) && C >= 512)) return 0;
+        if (has_red == 2 && !(patch_forms() & 4)) return 0;
+        if (has_pro && C >= 512 && !(patch_forms() & 1)) return 0;
+    }
     const int cs = dtype == DDMP_BF16 ? 64 : 32;
     return (C % cs == 0 && C >= 2 * cs && C <= 1024) ? 1 : 0;
 }
 
 namespace ddmp {
 
-// -> DDMP_OK, an error, or kPatchNotApplicable (the caller takes its slab kernel).  Needs the graph's patch tables, at most
-// 16 entries per row on average per chunk, C a multiple of the 128-byte slab and >= 2 slabs.
+// -> DDMP_OK, an error, or kPatchNotApplicable (the caller takes its slab kernel).  Needs the graph's patch tables, C a multiple
+// of the 128-byte slab and >= 2 slabs.  Fused epilogues: red_part + red_Yp = the BatchNorm-backward reductions; red_part without
+// red_Yp = the statistics form around red_mean.  The caller processes g->heavy with its own kernel.
 int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
                const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
                const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st) {
-    if (!ddmp_spmm_patch_selected(g, C, dtype, ps != nullptr, red_part != nullptr)) return kPatchNotApplicable;
+    const int kind = red_part ? (red_Yp ? 1 : 2) : 0;
+    if (!ddmp_spmm_patch_selected(g, C, dtype, ps != nullptr, kind)) return kPatchNotApplicable;
     RedArgs red{red_Yp, red_ldyp, red_scale, red_shift, red_mean, red_rstd, red_part};
     if (dtype == DDMP_BF16) {
         auto x = static_cast<const bf16_t*>(X);
         auto y = static_cast<bf16_t*>(Y);
-        if (red_part) return by_patch<bf16_t, false, true>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
-        if (ps) return by_patch<bf16_t, true, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
-        return by_patch<bf16_t, false, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        if (kind == 1) return by_patch<bf16_t, false, 1>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        if (kind == 2) return ps ? by_patch<bf16_t, true, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red)
+                                 : by_patch<bf16_t, false, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        if (ps) return by_patch<bf16_t, true, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+        return by_patch<bf16_t, false, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
     }
     auto x = static_cast<const float*>(X);
     auto y = static_cast<float*>(Y);
-    if (red_part) return by_patch<float, false, true>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
-    if (ps) return by_patch<float, true, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
-    return by_patch<float, false, false>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    if (kind == 1) return by_patch<float, false, 1>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    if (kind == 2) return ps ? by_patch<float, true, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red)
+                             : by_patch<float, false, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    if (ps) return by_patch<float, true, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+    return by_patch<float, false, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
 }
 
 }  // namespace ddmp

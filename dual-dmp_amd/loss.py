@@ -4,6 +4,7 @@
     mesh_laplacian_loss(pred_pos, mesh, ltype="rmse")         util/loss.py:37
     norm_rec_loss(pred_norm, real_norm, ltype="l1mae")        util/loss.py:55    float64 result
     fn_bnf_loss(pos, fn, mesh, ltype="l1mae", loop=5)         util/loss.py:86    -> (loss, new_fn)
+    bnf(fn, mesh, sigma_s=0.7, sigma_c=0.2, iter=1)           util/loss.py:195   -> (new_fn, new_mesh), numpy float64
     pos_norm_loss(pos, norm, mesh, ltype="mae")               util/loss.py:140
     mad(norm1, norm2)                                         util/loss.py:261   float64 numpy
 
@@ -477,6 +478,66 @@ def _variant_bnf(pos, fn, tb, ltype, loop):
         loss = (d.abs().sum(dim=1) ** 2).sum() / n
         loss = torch.sqrt(loss ** 2 + 1.0e-12)
     return loss, new_fn
+
+
+def bnf(fn, mesh, sigma_s=0.7, sigma_c=0.2, iter=1, device=None):
+    """Classical bilateral normal filtering + area-weighted vertex update (``util/loss.py:195-259``; dead in both drivers,
+    part of the module's surface) -> ``(new_fn float64 numpy [F,3], new_mesh)`` like the reference.
+
+    A device composition in float64 (the reference is numpy float64 with an O(V) Python loop per sweep): per sweep
+      * normals:  n_i <- normalise( sum_{j in f2f[i]} exp(-|c_j - c_i|^2 / 2 sigma_c^2) exp(-|n_j - n_i|^2 / 2 sigma_s^2)
+        a_j n_j ), ``+ 1e-12`` in the denominator, a ``-1`` slot of ``f2f`` gathers the LAST face (numpy's negative index,
+        as in ``fn_bnf_loss``);
+      * vertices: v <- v + sum_{f at v} a_f (n_f . (c_f - v)) n_f / sum_{f at v} a_f  with the centroids / areas of the
+        sweep's START (every vertex reads only itself: order-free);
+      * the new mesh's ``fc / fn / fa`` are recomputed after a sweep only when ``iter > 1`` (``:254-256``) -- with ``iter == 1``
+        the returned mesh keeps the input's, exactly as the reference leaves them.
+    ``fn``: tensor or ndarray; promoted to float64 (the reference keeps a float32 input for the first sweep's |n_j - n_i|:
+    float32 rounding of that distance only)."""
+    import copy
+    if device is None:
+        device = fn.device if isinstance(fn, torch.Tensor) and fn.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.DdmpError("bnf runs on the device: there is no CPU path")
+    with on_device(device):
+        f64 = dict(dtype=torch.float64, device=device)
+        new_fn = (fn.detach() if isinstance(fn, torch.Tensor) else torch.from_numpy(np.asarray(fn))).to(**f64).clone()
+        vs = torch.from_numpy(np.asarray(mesh.vs, dtype=np.float64)).to(device)
+        faces = torch.from_numpy(np.ascontiguousarray(mesh.faces, dtype=np.int64)).to(device)
+        F, V = faces.shape[0], vs.shape[0]
+        f2f = torch.from_numpy(np.ascontiguousarray(mesh.f2f, dtype=np.int64)).to(device)
+        f2f = torch.where(f2f < 0, f2f + F, f2f)                  # numpy's negative index
+        fc = torch.from_numpy(np.asarray(mesh.fc, dtype=np.float64)).to(device)
+        fa = torch.from_numpy(np.asarray(mesh.fa, dtype=np.float64)).to(device)
+        mesh_fn = None
+        corner_v = faces.reshape(-1)                             # corner 3 f + k belongs to vertex faces[f, k]
+        corner_f = torch.arange(F, device=device).repeat_interleave(3)
+        for _ in range(int(iter)):
+            fc_dist = (fc[f2f] - fc[:, None, :]).norm(dim=2)
+            neig_fn = new_fn[f2f]
+            fn_dist = (neig_fn - new_fn[:, None, :]).norm(dim=2)
+            w = torch.exp(-1.0 * fc_dist ** 2 / (2 * sigma_c ** 2)) * torch.exp(-1.0 * fn_dist ** 2 / (2 * sigma_s ** 2)) * fa[f2f]
+            new_fn = (w[:, :, None] * neig_fn).sum(1)
+            new_fn = new_fn / (new_fn.norm(dim=1, keepdim=True) + 1.0e-12)
+            nf, af = new_fn[corner_f], fa[corner_f]
+            t = (af * (nf * (fc[corner_f] - vs[corner_v])).sum(1))[:, None] * nf
+            incr = torch.zeros((V, 3), **f64).index_add_(0, corner_v, t)
+            area = torch.zeros(V, **f64).index_add_(0, corner_v, af)
+            touched = area > 0                                   # (a vertex of no face: the reference divides 0 / 0 -> nan)
+            vs = vs + torch.where(touched[:, None], incr / area[:, None], torch.full_like(incr, float("nan")))
+            if iter > 1:
+                fc = vs[faces].sum(1) / 3.0
+                cr = torch.cross(vs[faces[:, 1]] - vs[faces[:, 0]], vs[faces[:, 2]] - vs[faces[:, 0]], dim=1)
+                nrm = cr.norm(dim=1, keepdim=True)
+                fa = 0.5 * nrm[:, 0]
+                mesh_fn = cr / (nrm + 1e-24)
+        new_mesh = copy.copy(mesh)                               # (shares the connectivity tables; geometry replaced below)
+        new_mesh.vs = vs.cpu().numpy()
+        new_mesh.fc = np.array(mesh.fc, dtype=np.float64) if mesh_fn is None else fc.cpu().numpy()
+        new_mesh.fa = np.array(mesh.fa, dtype=np.float64) if mesh_fn is None else fa.cpu().numpy()
+        new_mesh.fn = np.array(mesh.fn, dtype=np.float64) if mesh_fn is None else mesh_fn.cpu().numpy()
+        return new_fn.cpu().numpy(), new_mesh
 
 
 def mad(norm1, norm2):

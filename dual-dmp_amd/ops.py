@@ -97,6 +97,14 @@ def trace_marker():
     check(_lib.lib().ddmp_trace_marker(_stream()), "ddmp_trace_marker")
 
 
+def copy_probe(src, dst, mode=0):
+    """Streaming device copy on the library's own kernel (bench.py's yardstick; mode 1: nontemporal)."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()
+    nbytes = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() >= nbytes
+    check(_lib.lib().ddmp_copy_probe(_p(src), _p(dst), nbytes, int(mode), _stream()), "ddmp_copy_probe")
+
+
 def set_gemm_mode(mode: int):
     """6 = bf16x6 split MFMA (f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA; 13 = f16x3 split MFMA
     in the row-panel kernels (f32-class accuracy, scaled operands: see gemm_next_scales), bf16x6 elsewhere."""

@@ -493,6 +493,9 @@ int ddmp_comm_allgather(ddmp_comm* comm, const void* send, void* recv, int64_t b
 /* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
 /* a one-thread kernel named ddmp_trace_marker_kernel: brackets a region in a rocprofv3 kernel trace (measurement aid) */
 int ddmp_trace_marker(ddmp_stream stream);
+/* measurement aid (bench.py's copy yardstick): a streaming device copy of `bytes` (multiple of 16, both pointers 16-byte
+ * aligned) written like the library's HBM-bound kernels; mode 0 plain, 1 nontemporal loads / stores */
+int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_stream stream);
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
 

@@ -11,6 +11,7 @@ It restates, in plain PyTorch-CPU / numpy, the algorithm of the reference
   --------------------------  ------------------------------------  ---------------------------
   mesh tables (python loops)  util/mesh.py:45-85,152-197            tests/golden/mesh_*.npz
   five losses, mad, fn        util/loss.py:16,37,55,86,140,261      tests/golden/loss_*.npz
+  bnf (filter + vertex move)  util/loss.py:195-259                  tests/golden/bnf_*.npz
                               util/mesh.py:87-92 util/models.py:5   (values AND gradients)
   GCNConv                     torch-geometric==2.2.0 (requirements  **PARITY UNPINNED**: PyG is an
                               .txt:19): gcn_norm + lin + propagate  un-vendored dependency that is
@@ -82,6 +83,35 @@ def face_normals_np(vs: np.ndarray, faces: np.ndarray):
     fa = 0.5 * np.sqrt((cr ** 2).sum(axis=1))
     fn = cr / (np.linalg.norm(cr, axis=1, keepdims=True) + 1e-24)
     return fn, fa
+
+
+def bnf_np(fn: np.ndarray, vs: np.ndarray, faces: np.ndarray, f2f: np.ndarray, fc: np.ndarray, fa: np.ndarray,
+           sigma_s=0.7, sigma_c=0.2, iters=1):
+    """Classical bilateral normal filter + area-weighted vertex update, ``util/loss.py:195-259`` restated with one
+    scatter instead of the per-vertex Python loop (:238-251).  ``fc`` / ``fa`` are the mesh's at entry and are recomputed
+    after a sweep only when ``iters > 1`` (:254-256); ``f2f`` = -1 gathers the last face (numpy indexing, :209-216).
+    -> (new_fn, new_vs, fc, fa)."""
+    new_fn = np.asarray(fn, dtype=np.float64)
+    vs = np.array(vs, dtype=np.float64)
+    fc, fa = np.asarray(fc, dtype=np.float64), np.asarray(fa, dtype=np.float64)
+    V = len(vs)
+    cv = faces.reshape(-1)
+    cf = np.repeat(np.arange(len(faces)), 3)
+    for _ in range(iters):
+        fc_dist = np.linalg.norm(fc[f2f] - fc[:, None, :], axis=2)
+        neig_fn = new_fn[f2f]
+        fn_dist = np.linalg.norm(neig_fn - new_fn[:, None, :], axis=2)
+        w = np.exp(-1.0 * fc_dist ** 2 / (2 * sigma_c ** 2)) * np.exp(-1.0 * fn_dist ** 2 / (2 * sigma_s ** 2)) * fa[f2f]
+        new_fn = np.sum(w[:, :, None] * neig_fn, 1)
+        new_fn = new_fn / (np.linalg.norm(new_fn, axis=1, keepdims=True) + 1.0e-12)
+        t = (fa[cf] * np.sum(new_fn[cf] * (fc[cf] - vs[cv]), 1))[:, None] * new_fn[cf]
+        incr = np.zeros((V, 3))
+        np.add.at(incr, cv, t)
+        vs = vs + incr / np.bincount(cv, weights=fa[cf], minlength=V)[:, None]
+        if iters > 1:
+            fc = np.sum(vs[faces], 1) / 3.0
+            _, fa = face_normals_np(vs, faces)
+    return new_fn, vs, fc, fa
 
 
 def mad_np(n1, n2) -> float:

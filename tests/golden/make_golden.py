@@ -5,6 +5,7 @@ Runs only in the build container (needs /root/reference); the GPU box and the te
 suite read the committed ``tests/golden/*.npz`` and never this script's imports.
 
 What is captured:
+  bnf_<name>.npz    ``loss.bnf`` (util/loss.py:195-259): filtered normals and the updated mesh, iter in {1, 3}
   mesh_<name>.npz   reference ``Mesh(path)`` arrays for small synthetic meshes
                     (util/mesh.py:8-21) + the OBJ text they were parsed from
                     + ``Mesh.save`` output text (util/mesh.py:267-285)
@@ -164,6 +165,16 @@ def main():
         l, _, g = grads(lambda p, n: RefLoss.pos_norm_loss(p, n, m, ltype="rmse"), pos, nrm)
         lv.update(pos_norm_rmse=l.numpy(), pos_norm_rmse_dpos=g[0].numpy(), pos_norm_rmse_dnorm=g[1].numpy())
         np.savez_compressed(os.path.join(HERE, "ltype_%s.npz" % name), **lv)
+
+        # ---------------- classical bilateral normal filter + vertex update (util/loss.py:195-259; dead in both drivers) ->
+        # bnf_<name>.npz: float64 input normals, iter in {1, 3}; and the float32-tensor input the signature also accepts
+        bv = {}
+        for it in (1, 3):
+            nf, nm = RefLoss.bnf(nrm.numpy().astype(np.float64), m, iter=it)
+            bv.update({"newfn_%d" % it: nf, "vs_%d" % it: nm.vs, "fc_%d" % it: nm.fc, "fa_%d" % it: nm.fa, "fn_%d" % it: nm.fn})
+        nf, nm = RefLoss.bnf(nrm, m, sigma_s=0.5, sigma_c=0.3, iter=2)
+        bv.update(newfn_f32in=nf, vs_f32in=nm.vs)
+        np.savez_compressed(os.path.join(HERE, "bnf_%s.npz" % name), **bv)
         print(name, "V", V, "F", F, "pos_rec", out["pos_rec"], out["pos_rec"].dtype,
               "lap", out["lap"], "norm_rec", out["norm_rec"], "bnf1", out["bnf1"],
               "bnf5", out["bnf5"], "pos_norm", out["pos_norm"], "mad", out["mad"])

@@ -339,3 +339,74 @@ def test_threaded_ranks_with_sharded_losses_match_unpartitioned(monkeypatch, ora
         assert float((p0 - p1).abs().max()) < 2e-5 and float((n0 - n1).abs().max()) < 2e-5
         assert abs(ref[1][0] - out[1][0]) <= 1e-2 * abs(ref[1][0]), (r, ref[1][0], out[1][0])
         assert torch.equal(results[r][1], results[0][1]) and torch.equal(results[r][2], results[0][2])
+
+
+# ------------------------------------------------------------------ the command line's loop with peers (round 5)
+def _cli_worker(rank, world, port, q, tmp):
+    """rank `rank` of `world` over gloo: cli.train_loop (the loop of main.py:86-149 / main4real.py:52-87) around a
+    DistributedTrainer on the CPU stand-in -- the part of `torchrun main.py` that has peers: every rank enters the evaluation's
+    all-gather at the same epochs, rank 0 alone logs, evaluates and writes the OBJ files."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import types
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, HERE)
+        sys.path.insert(0, os.path.dirname(HERE))
+        import cpu_ops_stub as stub
+        from conftest import load_oracle
+        from dual_dmp_amd import engine, trainer, networks, cli, dist as D, synth
+        from dual_dmp_amd.datamaker import dataset_from_meshes
+        for mod in (engine, trainer, networks):
+            mod.ops = stub
+        oracle = load_oracle()
+        v, f = synth.icosphere(2)
+        gt, noisy, smooth = synth.make_triplet(v, f)
+        data = dataset_from_meshes(noisy, smooth)
+        torch.manual_seed(0)
+        tr = D.make_distributed_trainer(noisy, smooth, data, torch.device("cpu"), rank, world, backend=D.TorchDistComm(), ops_mod=stub,
+                                        loss_engine=stub.OracleLossEngine(oracle, noisy, (3.0, 4.0, 4.0, 4.0, 1.0), 1))
+        tr.check_scales = lambda: 0                              # (f16x3 scale slots: HIP engines only)
+        calls, log = [], []
+
+        class Ev:
+            def mad(self, pos):
+                calls.append(int(pos.shape[0]))
+                fn, _ = oracle.face_normals_np(pos.double().numpy(), noisy.faces)
+                return oracle.mad_np(fn, gt.fn)
+        mesh_dic = {"gt_mesh": gt, "n_mesh": noisy, "o1_mesh": smooth, "mesh_name": "ico2"}
+        args = types.SimpleNamespace(iter=10)
+        out_dir = os.path.join(tmp, "out")
+        if rank == 0:
+            os.makedirs(out_dir, exist_ok=True)
+        # main.py: evaluation every 10 iterations (rank 0), no OBJ before iteration 100
+        mad = cli.train_loop(tr, args, mesh_dic, False, rank, world, Ev() if rank == 0 else object(), out_dir, log.append)
+        # main4real.py: an OBJ every 10 iterations, no evaluator
+        cli.train_loop(tr, types.SimpleNamespace(iter=10), dict(mesh_dic, gt_mesh=None), True, rank, world, None, out_dir, log.append)
+        q.put((rank, mad, calls, log, sorted(os.listdir(out_dir)) if rank == 0 else None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:          # noqa: BLE001
+        q.put((rank, repr(e), None, None, None))
+        raise
+
+
+def test_cli_loop_world2_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    got = {}
+    for _ in range(2):
+        rank, mad, calls, log, files = q.get(timeout=600)
+        assert calls is not None, mad
+        got[rank] = (mad, calls, log, files)
+    [p.join(60) for p in procs]
+    mad0, calls0, log0, files0 = got[0]
+    assert calls0 == [162] and got[1][1] == []                   # rank 0 evaluated the WHOLE mesh at iteration 10
+    assert got[1][2] == [] and any(s.startswith("initial_mad") for s in log0) and any(s.startswith("final_mad") for s in log0)
+    assert sum(s.startswith("Epoch") for s in log0) == 2         # 10 (main.py) + 10 (main4real.py)
+    assert files0 == ["10_ddmp.obj"] and 0.0 < mad0 < 40.0

@@ -80,6 +80,146 @@ def test_gemm_identities_at_1m():
     assert rel(y[rows], a[rows].double() @ w.double().t()) < 2e-6
 
 
+# ---- full-size kernel parity: every GEMM form and every gather form of the step AT 1,000,000 rows
+# against torch.float64 products computed on the GPU (test infrastructure: the product never calls torch matmul), rel-L2 <= 2e-6
+def _bn_coeffs(C, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    bn4 = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g),
+                       torch.rand(C, generator=g) + 0.5]).to(dev)
+    c10 = torch.stack([torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1]).to(dev)
+    return bn4, c10
+
+
+def _f(x64, a, b):
+    z = x64 * a.double() + b.double()
+    return torch.where(z > 0, z, 0.01 * z)
+
+
+def _dy(dz64, y64, bn4, c10):
+    z = y64 * bn4[0].double() + bn4[1].double()
+    return bn4[0].double() * dz64 * torch.where(z > 0, 1.0, 0.01) + c10[0].double() * y64 + c10[1].double()
+
+
+@pytest.mark.parametrize("M,K", [(512, 512), (512, 256), (128, 256)])
+def test_wgrad_forms_at_1m_vs_float64(M, K):
+    """dW[M,K] = g(G)^T f(Z) over 1,000,000 rows: plain, prologue on Z, BatchNorm backward rebuilt on the G load -- the
+    step's #1 kernel (gemm_tn_rm, split-K over 1M rows) at its real depth, all three operand forms."""
+    from dual_dmp_amd import ops
+    dev = torch.device("cuda:0")
+    n = FACES
+    torch.manual_seed(M + K)
+    G = torch.randn(n, M, device=dev)
+    Z = torch.randn(n, K, device=dev) * 1.5 + 0.2
+    bnK, _ = _bn_coeffs(K, dev, 1)
+    bnM, c10 = _bn_coeffs(M, dev, 2)
+    G64 = G.double()
+    ref = G64.t() @ Z.double()
+    assert rel(ops.gemm_tn(G, Z), ref) < 2e-6
+    ref = G64.t() @ _f(Z.double(), bnK[0], bnK[1])
+    assert rel(ops.gemm_tn(G, Z, pro=(bnK[0], bnK[1])), ref) < 2e-6
+    del ref, G64
+    if ops.gemm_tn_bnbwd_supported(M, K, n):
+        Yb = torch.randn(n, M, device=dev) * 2 + 0.5
+        ref = _dy(G.double(), Yb.double(), bnM, c10).t() @ Z.double()
+        assert rel(ops.gemm_tn_bnbwd(G, Yb, Z, bnM, c10), ref) < 2e-6
+
+
+@pytest.mark.parametrize("K,M", [(512, 512), (256, 512), (512, 256), (128, 256)])
+def test_forward_and_dgrad_forms_at_1m_vs_float64(K, M):
+    """Y = f(X) W^T (+bias) with the statistics epilogue, dX = dY W, dX = dY(dZ, Yb) W and the dgrad with the next layer's
+    BatchNorm-backward reductions in its epilogue, 1,000,000 rows."""
+    from dual_dmp_amd import ops
+    dev = torch.device("cuda:0")
+    n = FACES
+    torch.manual_seed(K * 3 + M)
+    X = torch.randn(n, K, device=dev)
+    W = torch.randn(M, K, device=dev) / K ** 0.5
+    bias = torch.randn(M, device=dev)
+    bnK, _ = _bn_coeffs(K, dev, 3)
+    bnM, c10 = _bn_coeffs(M, dev, 4)
+    ref = _f(X.double(), bnK[0], bnK[1]) @ W.double().t()
+    assert rel(ops.gemm_nt(X, W, pro=(bnK[0], bnK[1])), ref) < 2e-6
+    del ref
+    sums = torch.zeros(2 * M, dtype=torch.float64, device=dev)
+    Y = ops.gemm_nt_stats(X, W, sums, bias=bias)
+    ref = X.double() @ W.double().t() + bias.double()
+    assert rel(Y, ref) < 2e-6
+    yd = Y.double()
+    assert rel(sums, torch.cat([yd.sum(0), (yd * yd).sum(0)])) < 2e-6              # statistics of the values as stored
+    del ref, yd
+    dY = torch.randn(n, M, device=dev)
+    assert rel(ops.gemm_nn(dY, W), dY.double() @ W.double()) < 2e-6
+    if ops.gemm_bnbwd_supported(M, K, n):
+        Yb = torch.randn(n, M, device=dev) * 2 + 0.5
+        ref = _dy(dY.double(), Yb.double(), bnM, c10) @ W.double()
+        assert rel(ops.gemm_nn_bnbwd(dY, Yb, W, bnM, c10), ref) < 2e-6
+        del ref, Yb
+    if ops.gemm_nn_bnred_supported(M, K, n):
+        Yp = torch.randn(n, K, device=dev) * 2 + 0.3
+        sums = torch.zeros(2 * K, dtype=torch.float64, device=dev)
+        out = ops.gemm_nn_bnred(dY, W, Yp, bnK, sums)
+        assert rel(out, dY.double() @ W.double()) < 2e-6
+        od, yd = out.double(), Yp.double()
+        gg = od * torch.where(yd * bnK[0].double() + bnK[1].double() > 0, 1.0, 0.01)
+        want = torch.cat([gg.sum(0), (gg * (yd - bnK[2].double()) * bnK[3].double()).sum(0)])
+        assert rel(sums, want) < 2e-5
+
+
+@pytest.mark.parametrize("which", ["vertex", "face"])
+def test_gather_forms_at_c512_vs_float64(big, which):
+    """Every form of the gather the step launches, C = 512, on the 1M-face mesh's two graphs (engine numbering: RCB) against
+    a float64 aggregation on the GPU (index_add over the CSR entries, 128 channels at a time)."""
+    from dual_dmp_amd import ops, synth
+    dev = torch.device("cuda:0")
+    gt, noisy, smooth, data = big
+    v, f = synth.rcb_relabel(noisy.vs, noisy.faces)
+    from dual_dmp_amd.mesh import Mesh
+    m = Mesh(vs=v, faces=f)
+    if which == "vertex":
+        e = torch.tensor(m.edges.T, dtype=torch.long)
+        idx, n = torch.cat([e, e[[1, 0]]], 1).to(dev), len(v)
+    else:
+        idx, n = torch.from_numpy(m.f_edges).to(dev), len(f)
+    g = ops.graph_for(idx, n)
+    src = torch.cat([idx[0], torch.arange(n, device=dev)])
+    dst = torch.cat([idx[1], torch.arange(n, device=dev)])
+    deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, dst, torch.ones(len(dst), dtype=torch.float64, device=dev))
+    w = deg[src].pow(-0.5) * deg[dst].pow(-0.5)
+
+    def agg(x64):
+        out = torch.zeros_like(x64)
+        for c in range(0, x64.shape[1], 128):
+            out[:, c:c + 128].index_add_(0, dst, x64[src, c:c + 128] * w[:, None])
+        return out
+
+    C = 512
+    torch.manual_seed(7)
+    x = torch.randn(n, C, device=dev)
+    bn4, c10 = _bn_coeffs(C, dev, 5)
+    bias = torch.randn(C, device=dev)
+    y = ops.spmm(g, x)
+    assert rel(y, agg(x.double())) < 2e-6
+    ref = agg(_f(x.double(), bn4[0], bn4[1])) + bias.double()
+    yp = ops.spmm(g, x, bias=bias, pro=(bn4[0], bn4[1]))
+    assert rel(yp, ref) < 2e-6
+    out = torch.empty_like(y)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    ops.spmm_stats(g, x, out, (ref.mean(0) * 1.01).float().contiguous(), sums, bias=bias, pro=(bn4[0], bn4[1]))
+    assert torch.equal(out, yp)
+    od = out.double()
+    assert rel(sums, torch.cat([od.sum(0), (od * od).sum(0)])) < 2e-6
+    del ref, od
+    yb = torch.randn(n, C, device=dev) * 2 + 0.3
+    ops.spmm_bnred(g, x, out, yb, bn4, sums)
+    assert torch.equal(out, y)
+    od, yd = out.double(), yb.double()
+    gg = od * torch.where(yd * bn4[0].double() + bn4[1].double() > 0, 1.0, 0.01)
+    assert rel(sums, torch.cat([gg.sum(0), (gg * (yd - bn4[2].double()) * bn4[3].double()).sum(0)])) < 2e-5
+    del od, gg
+    ops.spmm_bnbwd(g, x, yb, bn4, c10, out)
+    assert rel(out, agg(_dy(x.double(), yd, bn4, c10))) < 2e-6
+
+
 def test_batchnorm_normalises_at_1m():
     from dual_dmp_amd import ops
     dev = torch.device("cuda:0")

@@ -88,12 +88,13 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
     features on graphs with <= 8 entries per row from 64k rows at C >= 256 (plain) / C = 256 (prologue).  144,400-face torus,
     FACE graph (4 entries per row: NE = 4) and VERTEX graph (7 entries: NE = 8): the route is asserted, results against a
     float64 sparse product and -- same sums in the same order -- bit for bit against the lean gather's; fused reductions and
-    the narrow widths stay on the lean gather."""
+    the narrow widths stay on the lean gather.  Round 5: the prologue at C = 512, the fused reduction at C = 512 and the
+    statistics form (C >= 256) take this kernel too."""
     from dual_dmp_amd import ops, synth, _lib
     from dual_dmp_amd.mesh import Mesh
     if os.environ.get("DDMP_SPMM_PATCH") == "0":
         pytest.skip("LDS-patch gather switched off")
-    v, f = synth.morton_relabel(*synth.torus(380, 190))          # (the engines relabel along a Morton curve: compact patches)
+    v, f = synth.rcb_relabel(*synth.torus(380, 190))             # (the engines relabel by coordinate bisection: compact patches)
     m = Mesh(vs=v, faces=f)
     fi = torch.from_numpy(m.f_edges)
     e = torch.tensor(m.edges.T, dtype=torch.long)
@@ -103,9 +104,11 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         g = ops.graph_for(ei.to(dev), n)
         sel = L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1       # (144,400 faces / 72,200 vertices: both from 64k rows)
         assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
-        if os.environ.get("DDMP_SPMM_PATCH") is None:
-            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
+        if os.environ.get("DDMP_SPMM_PATCH") is None and os.environ.get("DDMP_SPMM_PATCH_FORMS") is None:
+            # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256
+            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
             assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 2) == 1
         # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
         src = torch.cat([ei[0], torch.arange(n)])
         dst = torch.cat([ei[1], torch.arange(n)])

@@ -146,6 +146,16 @@ def test_non_default_ltypes_match_reference_golden(dev, golden_dir, name):
 
 
 # ------------------------------------------------------------------------------------ nets
+def _flipped(vf, hub):
+    from dual_dmp_amd import synth
+    v, f = vf
+    f = synth.flip_edges(v, f, rounds=10, seed=1)
+    f = synth.add_hub(v, f, hub, 24)
+    hist = synth.valence_histogram(f, len(v))
+    assert len(hist) - 1 == 24 and hist[3] > 0 and hist[10:].sum() > 1, hist
+    return v, f
+
+
 def _case(dev, which="ico3"):
     from dual_dmp_amd import synth
     from dual_dmp_amd.datamaker import dataset_from_meshes
@@ -153,16 +163,21 @@ def _case(dev, which="ico3"):
             "cad33": lambda: synth.cube_cad(33),         # 13,068 faces: the fandisk stand-in (README.md:57 of the reference)
             "grid24": lambda: synth.open_grid(24, 17),
             "torus48k": lambda: synth.torus(220, 110),   # 48,400 faces / 24,200 verts: row-panel routes on both graphs
-            "torus144k": lambda: synth.torus(380, 190)}[which]()   # 144,400 faces / 72,200 verts: every bench route is on
+            "torus144k": lambda: synth.torus(380, 190),  # 144,400 faces / 72,200 verts: every bench route is on
+            # irregular valence (round 5): random edge flips (valence 3 ... 12+) and a valence-24 hub
+            "flip": lambda: _flipped(synth.torus(30, 14), 17),
+            "flip144k": lambda: _flipped(synth.torus(380, 190), 1000)}[which]()
     v, f = synth.permute_vertices(v, f, 3)
     gt, noisy, smooth = synth.make_triplet(v, f)
     return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
 
 
+@pytest.mark.parametrize("mesh", ["grid", "flip"])
 @pytest.mark.parametrize("cin,cout", [(16, 32), (7, 32), (64, 32), (512, 256), (32, 3), (5, 6)])
-def test_gcnconv_dropin_matches_oracle(dev, oracle, cin, cout):
+def test_gcnconv_dropin_matches_oracle(dev, oracle, cin, cout, mesh):
+    """``mesh`` = "flip": a flipped torus with a valence-24 hub -- rows of 4 ... 25 entries (round 5)."""
     from dual_dmp_amd.nn_ops import GCNConv
-    _, noisy, _, data = _case(dev, "grid")
+    _, noisy, _, data = _case(dev, mesh)
     torch.manual_seed(cin * cout)
     ref = oracle.GCNConvRef(cin, cout)
     with torch.no_grad():
@@ -354,6 +369,22 @@ def test_bench_routes_teacher_forced_beside_the_oracle_at_144k(dev, oracle):
     if os.environ.get("DDMP_GEMM_PANEL") == "0" or ops.get_gemm_mode() != 13:
         pytest.skip("not the default GEMM configuration")
     _teacher_forced(dev, oracle, "torus144k", DEFAULT_K, 1, 0, 2, (1, 2), expect_fused=True)
+
+
+def test_irregular_mesh_teacher_forced_at_144k(dev, oracle):
+    """the same teacher-forced check of main.py:88-110 on an IRREGULAR mesh -- the 144,400-face torus
+    after ten rounds of random manifold-preserving edge flips (valence 3 ... 12+) with a valence-24 hub; the vertex graph has
+    rows of 4 ... 25 entries, both graphs are above every fused-route threshold (asserted), the LDS-patch gather runs with
+    register entries + LDS tails.  Iteration 1 against oracle.train_step in float32 and the oracle's float64 gradients."""
+    from dual_dmp_amd import ops
+    if os.environ.get("DDMP_GEMM_PANEL") == "0" or ops.get_gemm_mode() != 13:
+        pytest.skip("not the default GEMM configuration")
+    _teacher_forced(dev, oracle, "flip144k", DEFAULT_K, 1, 0, 1, (1,), expect_fused=True)
+
+
+def test_irregular_small_mesh_teacher_forced(dev, oracle):
+    """The small flipped mesh (840 faces, a valence-24 hub), BNF gate open, bnfloop 5: iterations 1, 2, 4."""
+    _teacher_forced(dev, oracle, "flip", DEFAULT_K, 5, 100, 4, (1, 2, 4))
 
 
 def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect_fused=False):
@@ -686,6 +717,30 @@ def test_main_trains_on_the_preprocess_output(dev, tmp_path, monkeypatch, capsys
     assert "initial_mad:" in out and "final_mad:" in out and tr.epoch == 20
     init, final = (float(out.split(k)[1].split()[0]) for k in ("initial_mad:", "final_mad:"))
     assert final < init                                              # 20 iterations already denoise the sphere
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_bnf_matches_reference_golden(dev, golden_dir, name):
+    """loss.bnf (util/loss.py:195-259: classical bilateral normal filter + area-weighted vertex update) as a float64 device
+    composition vs the reference's numpy run: filtered normals, moved vertices, and the returned mesh's fc / fa / fn (the
+    input's when iter == 1, recomputed when iter > 1)."""
+    from dual_dmp_amd import loss as L
+    gb = np.load(os.path.join(golden_dir, "bnf_%s.npz" % name))
+    gl = np.load(os.path.join(golden_dir, "loss_%s.npz" % name))
+    gm = np.load(os.path.join(golden_dir, "mesh_%s.npz" % name))
+    m = types.SimpleNamespace(**{k: gm[k] for k in ("vs", "faces", "edges", "f2f", "fn", "fc", "fa")})
+    vs0 = m.vs.copy()
+    for it in (1, 3):
+        nf, nm = L.bnf(torch.from_numpy(gl["norm"]).double().to(dev), m, iter=it)
+        assert isinstance(nf, np.ndarray) and nf.dtype == np.float64
+        np.testing.assert_allclose(nf, gb["newfn_%d" % it], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(nm.vs, gb["vs_%d" % it], rtol=1e-9, atol=1e-11)
+        for k in ("fc", "fa", "fn"):
+            np.testing.assert_allclose(getattr(nm, k), gb["%s_%d" % (k, it)], rtol=1e-9, atol=1e-11)
+    assert np.array_equal(m.vs, vs0)                                             # the input mesh is not modified
+    nf, nm = L.bnf(gl["norm"], m, sigma_s=0.5, sigma_c=0.3, iter=2)              # numpy float32 input, no device given
+    np.testing.assert_allclose(nf, gb["newfn_f32in"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(nm.vs, gb["vs_f32in"], rtol=0, atol=2e-6)
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -17,6 +17,10 @@ SWITCHES = [
     {"DDMP_SPMM_PATCH": "0"},                  # lean gather everywhere
     {"DDMP_SPMM_PATCH": "1"},                  # LDS-patch gather wherever it applies (incl. its fused-reduction form)
     {"DDMP_SPMM_PATCH_NE": "0"},               # ... with the entries read from LDS per slab
+    {"DDMP_SPMM_PATCH_FORMS": "0"},            # round-4 selection: no prologue / reduction at C = 512, no statistics form on it
+    {"DDMP_SPMM": "row"},                      # round-1 row kernel for every width
+    {"DDMP_SPMM_SL": "2"},                     # two 128-byte slabs per pass of the round-2 slab kernel
+    {"DDMP_ASYNC_WGRAD": "1"},                 # weight gradients on a further stream
     {"DDMP_SPMM_LEAN": "0"},                   # round-2 slab gather
     {"DDMP_GEMM_RR": "0"},                     # row-panel instead of row-register GEMMs
     {"DDMP_GEMM_BNRED": "0"},                  # dgrad without the reductions epilogue

@@ -102,6 +102,23 @@ def test_metric_matches_reference(oracle, golden_dir, name):
     np.testing.assert_allclose(gl["models_compute_fn"], fn, atol=2e-6)
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_bnf_matches_reference(oracle, golden_dir, name):
+    """util/loss.py:195-259 (classical bilateral normal filter + vertex update; round 5)."""
+    gb = _load(golden_dir, "bnf", name)
+    gl = _load(golden_dir, "loss", name)
+    gm = _load(golden_dir, "mesh", name)
+    for it in (1, 3):
+        nf, vs, fc, fa = oracle.bnf_np(gl["norm"].astype(np.float64), gm["vs"], gm["faces"], gm["f2f"], gm["fc"], gm["fa"], iters=it)
+        np.testing.assert_allclose(nf, gb["newfn_%d" % it], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(vs, gb["vs_%d" % it], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(fc, gb["fc_%d" % it], rtol=1e-10, atol=1e-12)     # iter 1: the input mesh's, untouched
+        np.testing.assert_allclose(fa, gb["fa_%d" % it], rtol=1e-10, atol=1e-12)
+    nf, vs, _, _ = oracle.bnf_np(gl["norm"], gm["vs"], gm["faces"], gm["f2f"], gm["fc"], gm["fa"], 0.5, 0.3, 2)
+    np.testing.assert_allclose(nf, gb["newfn_f32in"], rtol=0, atol=2e-6)             # float32 input: first-sweep |dn| in float32
+    np.testing.assert_allclose(vs, gb["vs_f32in"], rtol=0, atol=2e-6)
+
+
 def test_gcnconv_pyg_shape_vs_dense(oracle, golden_dir):
     """The PyG-shaped restatement against the independent float64 dense form
     (parity with real PyG is unpinned: the package is absent, see oracle header)."""
