@@ -797,8 +797,24 @@ def main():
         torch_copy_gbs = copy_rate(lambda: dst.copy_(src))
         probe = {"plain": copy_rate(lambda: ops.copy_probe(src, dst, 0)), "nontemporal": copy_rate(lambda: ops.copy_probe(src, dst, 1))}
         copy_gbs = max(probe.values())
+        # ... and in the gather's access pattern (64-row chunks walked one 128-byte slab at a time) at the step's row widths
+        slab = {}
+        for Cw in (512, 256, 128, 64, 32):
+            rows_ = (1 << 29) // Cw                              # 2 GiB read + 2 GiB written at every width (beyond the 256 MB MALL)
+            a_, b_ = src[: rows_ * Cw].view(rows_, Cw), dst[: rows_ * Cw].view(rows_, Cw)
+            ops.copy_probe_rows(a_, b_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.copy_probe_rows(a_, b_)
+            e1.record()
+            torch.cuda.synchronize()
+            slab[str(Cw)] = round(5 * 2.0 * a_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         out["device_copy"] = {"ddmp_copy_probe_GBs": {k: round(v, 1) for k, v in probe.items()}, "torch_copy__GBs": round(torch_copy_gbs, 1),
                               "guide_float4_copy_GBs": GUIDE_COPY_GBS,
+                              "slab_pattern_copy_GBs_by_row_width": slab,
+                              "slab_pattern_what": "ddmp_copy_probe_rows: 2 GiB of float32 rows of that width copied in the gather's own "
+                                                   "access pattern (64-row chunks, one 128-byte slab at a time): the pattern's ceiling",
                               "what": "2 GiB read + 2 GiB written; frac_of_device_copy below divides by the better ddmp_copy_probe figure"}
         del src, dst
         torch.cuda.empty_cache()

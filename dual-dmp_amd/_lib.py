@@ -90,7 +90,7 @@ def lib():
             raise DdmpError("libddmp_hip.so does not export %s (declared in include/ddmp_hip.h)" % name)
         fn.restype = _RET[ret]
         fn.argtypes = [t for t, _ in sig]
-    if handle.ddmp_abi_version() != 2:
+    if handle.ddmp_abi_version() != 3:
         raise DdmpError("libddmp_hip.so ABI version mismatch")
     _lib = handle
     return _lib

@@ -74,6 +74,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // belong in the same step (irregular meshes: a step of 8 rows costs its LONGEST row; sorted, the long rows share a few steps).
 // All keys equal (regular meshes): the identity, at the price of two wave reductions.
 __device__ __forceinline__ int chunk_rank_desc(int key, int lane) {
+    // regular meshes: every key equal -- decided with one ballot, no cross-lane traffic
+    if (__ballot(key != __builtin_amdgcn_readfirstlane(key)) == 0ull) return lane;
     int kmax = key, kmin = key;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -82,7 +84,6 @@ __device__ __forceinline__ int chunk_rank_desc(int key, int lane) {
     }
     kmax = __builtin_amdgcn_readfirstlane(kmax);
     kmin = __builtin_amdgcn_readfirstlane(kmin);
-    if (kmax == kmin) return lane;
     int rank = 0;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int v = kmax; v >= kmin; --v) {                         // (uniform: at most 33 rounds)
@@ -91,6 +92,20 @@ __device__ __forceinline__ int chunk_rank_desc(int key, int lane) {
         else if (key == v) rank += __popcll(m & below);
     }
     return rank;
+}
+
+// Sum over the 8 lanes l, l ^ 8, l ^ 16, l ^ 32 ... that share (lane & 7) -- the 8 row groups of a wave in the gather kernels'
+// fused-reduction epilogues.  __shfl_xor compiles to ds_bpermute_b32 (the LDS crossbar: 24 of them per wave and 128-byte slab
+// were a third of the statistics epilogue's cost on the 7-entry vertex graph); here one DPP add within the 16-lane row and the
+// two gfx950 lane-swap instructions.  Same pairings in the same order as the shuffle tree: bit-identical sums.
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+    unsigned a = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);     // rows 0 <-> 1, 2 <-> 3 (16-lane rows)
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    a = __float_as_uint(v);
+    const auto t = __builtin_amdgcn_permlane32_swap(a, a, false, false);     // lower <-> upper half
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
 // block-level sum of one double per thread; result valid in thread 0. `sm` holds >= blockDim/64 doubles.

@@ -73,6 +73,44 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const uint4* __restrict
         }
     }
 }
+// The same bytes in the GATHER's access pattern: a workgroup owns 64 consecutive rows of a row-major [n_rows, row_bytes] matrix
+// and walks them one 128-byte slab at a time (8 lanes x 16 bytes per row, 8 rows per wave instruction, nontemporal stores) --
+// what spmm_lean / spmm_patch do minus the gather itself.  Its rate is the ceiling of that pattern on this box: the distance to
+// the streaming copy above is what walking 1-2 KB rows slab by slab costs in HBM efficiency, whatever the graph is.
+__global__ __launch_bounds__(256) void copy_probe_rows_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                              int n_rows, int row_bytes, int chunks_per_xcd, int n_chunks) {
+    typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+    const int chunk = (blockIdx.x & (ddmp::kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
+    if (chunk >= n_chunks) return;
+    const int r0 = chunk * 64, nr = min(64, n_rows - r0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 3, sl = lane & 7;
+    for (int b0 = 0; b0 < row_bytes; b0 += 128) {
+        uint4 v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lr = min(wave * 8 + grp + 32 * q, nr - 1);
+            v[q] = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + lr) * row_bytes + b0 + sl * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lr = wave * 8 + grp + 32 * q;
+            if (lr < nr) {
+                nt_u4 t = {v[q].x, v[q].y, v[q].z, v[q].w};
+                __builtin_nontemporal_store(t, reinterpret_cast<nt_u4*>(dst + (int64_t)(r0 + lr) * row_bytes + b0 + sl * 16));
+            }
+        }
+    }
+}
+extern "C" int ddmp_copy_probe_rows(const void* src, void* dst, int64_t n_rows, int row_bytes, ddmp_stream stream) {
+    ARG_TRY(src && dst && n_rows > 0 && n_rows < (int64_t)INT32_MAX && row_bytes >= 128 && row_bytes % 128 == 0);
+    ARG_TRY(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
+    const int n_chunks = (int)((n_rows + 63) / 64), cpx = (n_chunks + ddmp::kXcd - 1) / ddmp::kXcd;
+    hipLaunchKernelGGL(copy_probe_rows_kernel, dim3(cpx * ddmp::kXcd), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src,
+                       (unsigned char*)dst, (int)n_rows, row_bytes, cpx, n_chunks);
+    LAUNCH_TRY();
+    return DDMP_OK;
+}
+
 extern "C" int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_stream stream) {
     ARG_TRY(src && dst && bytes > 0 && bytes % 16 == 0 && (mode == 0 || mode == 1));
     ARG_TRY(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);

@@ -303,12 +303,18 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         }
         if (RED) {                                               // per chunk: ONE partial record per channel (round 4: the four
 #pragma unroll                                                   // waves' sums meet in LDS -- a quarter of the partial traffic,
-            for (int j = 0; j < VW; ++j)                         // which was 17 % of the tensor bytes at C = 512 in bf16)
+            for (int j = 0; j < VW; ++j) {                       // which was 17 % of the tensor bytes at C = 512 in bf16)
+                if (LANES == 8) {                                // (DPP + lane swaps instead of the LDS crossbar: ddmp_common.h)
+                    q0[j] = group8_sum(q0[j]);
+                    q1[j] = group8_sum(q1[j]);
+                } else {
 #pragma unroll
-                for (int o = LANES; o < 64; o <<= 1) {
-                    q0[j] += __shfl_xor(q0[j], o, 64);
-                    q1[j] += __shfl_xor(q1[j], o, 64);
+                    for (int o = LANES; o < 64; o <<= 1) {
+                        q0[j] += __shfl_xor(q0[j], o, 64);
+                        q1[j] += __shfl_xor(q1[j], o, 64);
+                    }
                 }
+            }
             if (grp == 0) {
 #pragma unroll
                 for (int j = 0; j < VW; ++j) {

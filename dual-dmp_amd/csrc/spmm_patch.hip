@@ -333,12 +333,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         }
         if (RED) {                                               // this wave's 16 rows -> LDS; the record: next slab (record())
 #pragma unroll
-            for (int j = 0; j < VW; ++j)
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-                    q0[j] += __shfl_xor(q0[j], o, 64);
-                    q1[j] += __shfl_xor(q1[j], o, 64);
-                }
+            for (int j = 0; j < VW; ++j) {
+                q0[j] = group8_sum(q0[j]);
+                q1[j] = group8_sum(q1[j]);
+            }
             if (grp == 0) {
                 float* sp = s_part + (((s & 1) * 4 + wave) * 2) * CS + sl * VW;
 #pragma unroll

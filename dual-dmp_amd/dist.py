@@ -726,7 +726,9 @@ class DistributedTrainer:
     def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
                  bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None, use_graph=None):
-        """``use_graph`` (default: env DDMP_DIST_GRAPH=1): replay the partitioned iteration as ONE hipGraph -- every kernel and,
+        """``use_graph`` (default: env DDMP_DIST_GRAPH=1; it OVERRIDES DDMP_DIST_STREAMS: a captured iteration uses one
+        communicator on one stream; with more than one rank it is refused unless DDMP_DIST_GRAPH_PEERS=1, see below): replay the
+        partitioned iteration as ONE hipGraph -- every kernel and,
         with the native RCCL backend, every collective is enqueued on the capturing stream(s) from C (csrc/comm.hip); the Adam
         step count lives on the device as in FusedTrainer(use_graph=True).  First call eager, second captured, then replayed;
         re-captured when the BNF gate opens.  Native backend only (torch.distributed's collectives are issued from Python).
@@ -747,6 +749,15 @@ class DistributedTrainer:
         if use_graph is None:
             use_graph = os.environ.get("DDMP_DIST_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and isinstance(backend, NativeComm) and torch.device(device).type == "cuda"
+        if self.use_graph and backend.world_size > 1 and os.environ.get("DDMP_DIST_GRAPH_PEERS") != "1":
+            # capturing RCCL send / recv and all-reduces into a hipGraph has only ever run on a one-rank loopback
+            # communicator (no multi-GPU box in the build loop), the start-up self-check validates EAGER exchanges only, and a hang
+            # inside a capture or a replay is not covered by its watchdog.  With peers the capture is refused until someone has
+            # validated it on hardware: DDMP_DIST_GRAPH_PEERS=1 takes that responsibility.
+            import warnings
+            warnings.warn("DDMP_DIST_GRAPH / use_graph with %d ranks: the captured iteration is unvalidated with peers -- running "
+                          "eagerly (set DDMP_DIST_GRAPH_PEERS=1 to capture anyway)" % backend.world_size)
+            self.use_graph = False
         if self.use_graph:
             # ONE communicator on ONE stream under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1
             # (tests/test_gpu_multi.py): the captured iteration replays correctly with one communicator; with a second

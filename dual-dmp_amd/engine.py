@@ -250,7 +250,7 @@ class GcnEngine:
         self._wplanes = None
         self._prep_weights = (dtype == torch.float32 and hasattr(ops, "gemm_prepare_weights")
                               and os.environ.get("DDMP_PREP_WEIGHTS", "1") != "0")
-        self._tail_fused = (isinstance(self.comm, NoComm) and hasattr(ops, "bn_next_prepare")
+        self._tail_fused = (isinstance(self.comm, NoComm) and hasattr(ops, "BnFwd")
                             and os.environ.get("DDMP_TAIL_FUSE", "1") != "0")
         # f16 split GEMM modes: one scale slot per layer and GEMM operand (0: the forward operand X, 1: the gradient
         # operand); the kernels record the operand maxima of this iteration, backward() rolls them into the scales
@@ -289,9 +289,10 @@ class GcnEngine:
         return self._flat[i][: self.n_cols * c].view(self.n_cols, c)
 
     def _scales(self, l, a, b=None):
-        """Name the operand scale slots of the next GEMM call (f16 split modes only)."""
+        """Keyword of a GEMM call: its operands' scale slots (f16 split modes only; an explicit per-call option, ABI 3)."""
         if self._f16:
-            ops.gemm_next_scales(self._slot[l][a], None if b is None else self._slot[l][b], self._prime)
+            return {"scales": (self._slot[l][a], None if b is None else self._slot[l][b], self._prime)}
+        return {}
 
     def check_scales(self) -> int:
         """f16 split modes.  An operand that outgrows its (one iteration old) scale is never computed with clamped:
@@ -371,10 +372,8 @@ class GcnEngine:
         two nets' generators alternately, so that one net's collective is in flight while the other net computes
         (dist.interleave); the plain forward() above waits immediately.  The result is left in ``self.out``."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
-        if hasattr(ops, "next_cancel"):
-            ops.next_cancel()                                     # nothing armed by an aborted earlier pass survives
         self.n_forward = getattr(self, "n_forward", 0) + 1        # (dist: cache key of the all-gathered outputs)
-        self._f16 = hasattr(ops, "gemm_next_scales") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
+        self._f16 = hasattr(ops, "gemm_scales_roll") and self.dtype == torch.float32 and ops.get_gemm_mode() == 13
         self._prepare_weights(params)
         X, pro = self.x0, None
         halo_started = False
@@ -386,9 +385,9 @@ class GcnEngine:
             W = L.view(params, "conv%d.lin.weight" % i, true_shape=False)
             b = L.view(params, "conv%d.bias" % i)
             Y = self.Y[l]
-            if tail:
-                ops.bn_next_prepare(self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i), self.bn4[l],
-                                    running=(self.running[l][0], self.running[l][1]) if update_running else None)
+            # one device: this layer's BatchNorm coefficients come from the second stage of whichever call reduces Y
+            bnk = {"bn": ops.BnFwd(self.n_total, L.view(params, "bn%d.weight" % i), L.view(params, "bn%d.bias" % i), self.bn4[l],
+                                   running=(self.running[l][0], self.running[l][1]) if update_running else None)} if tail else {}
             if self.agg_first[l]:
                 P = self.P[l]
                 if l > 0 or not self._p1_ready:
@@ -396,22 +395,20 @@ class GcnEngine:
                         yield comm.start_halo(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
                     self._p1_ready = True
-                self._scales(l, 0)
                 if hasattr(ops, "gemm_nt_stats"):                # BatchNorm statistics from the GEMM epilogue
-                    ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n, **self._wp(l, 0))
+                    ops.gemm_nt_stats(P, W, self.sums, out=Y, bias=b, n_rows=n, **self._wp(l, 0), **self._scales(l, 0), **bnk)
                 else:
                     ops.gemm_nt(P, W, out=Y, bias=b, n_rows=n)
-                    ops.bn_stats(Y, sums=self.sums, n_rows=n)
+                    ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
             else:
                 H = self._work(0, L.cout[l])
-                self._scales(l, 0)
-                ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0))
+                ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0), **self._scales(l, 0))
                 yield comm.start_halo(H, n)
                 if self.fuse_spmm_stats[l]:
-                    ops.spmm_stats(g, H, Y[:n], self.bn4[l][2], self.sums, bias=b)
+                    ops.spmm_stats(g, H, Y[:n], self.bn4[l][2], self.sums, bias=b, **bnk)
                 else:
                     ops.spmm(g, H, out=Y[:n], bias=b)
-                    ops.bn_stats(Y, sums=self.sums, n_rows=n)
+                    ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
             # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
             # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
             halo_started = l < 11 and self.agg_first[l + 1]
@@ -448,8 +445,6 @@ class GcnEngine:
         work buffer it reads), so that every event the main stream waits on is the TAIL of the side stream -- the first
         form of this (several in flight, buffers guarded by mid-stream events) made hipStreamEndCapture crash."""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
-        if hasattr(ops, "next_cancel"):
-            ops.next_cancel()
         side = self._side_stream() if self.async_wgrad else None
         free = list(range(len(self._flat)))                     # FIFO: a buffer read by the wgrad in flight is reused last
         pending = [None]                                        # (completion event, work buffers it reads) of that wgrad
@@ -473,7 +468,6 @@ class GcnEngine:
         def wgrad(l, fn, *bufs):
             """fn() launches the weight-gradient GEMM of layer l; bufs = work buffers it reads."""
             if side is None:
-                self._scales(l, 1, 0)
                 fn()
                 return
             join()
@@ -481,7 +475,6 @@ class GcnEngine:
             ev.record(torch.cuda.current_stream())
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                self._scales(l, 1, 0)
                 fn()
                 done = torch.cuda.Event()
                 done.record(side)
@@ -493,10 +486,12 @@ class GcnEngine:
         tail = self._tail_fused
 
         def arm(l):
-            """Layer l's BatchNorm-backward coefficients come with the reduction launched next (one device)."""
+            """Keyword of the call that reduces for layer l: its BatchNorm-backward coefficients come from that call's second
+            stage (one device; an explicit per-call option, ABI 3)."""
             if tail:
-                ops.bn_next_bwd_prepare(self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % (l + 1)),
-                                        L.view(grads, "bn%d.bias" % (l + 1)), self.c10s[l])
+                return {"bn": ops.BnBwd(self.n_total, self.bn4[l], L.view(grads, "bn%d.weight" % (l + 1)),
+                                        L.view(grads, "bn%d.bias" % (l + 1)), self.c10s[l])}
+            return {}
 
         # the conv-bias gradients: zero after BatchNorm in exact arithmetic (its backward output has zero column mean), where
         # the reference's autograd leaves float32 summation noise.  Written as 0 on every route, in one launch
@@ -516,8 +511,7 @@ class GcnEngine:
         def spmm_to_dz(src, dst, l):
             """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""
             if fuse_red and l > 0:
-                arm(l - 1)
-                ops.spmm_bnred(g, src, dst[:n], self.Y[l - 1], self.bn4[l - 1], self.sums)
+                ops.spmm_bnred(g, src, dst[:n], self.Y[l - 1], self.bn4[l - 1], self.sums, **arm(l - 1))
                 return True
             ops.spmm(g, src, out=dst[:n])
             return False
@@ -535,10 +529,10 @@ class GcnEngine:
             from the GEMM epilogue where the kernel exists (across devices too: the epilogue sums this rank's owned rows,
             which is what n selects, and the sums are all-reduced as after the separate pass)."""
             if fuse_dgrad_red and ops.gemm_nn_bnred_supported(L.cout[l], L.cin_p[l], n, self.dtype):
-                arm(l - 1)
-                ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n, **self._wp(l, 1))
+                ops.gemm_nn_bnred(dH, W, self.Y[l - 1], self.bn4[l - 1], self.sums, out=dZ, n_rows=n, **self._wp(l, 1),
+                                  **self._scales(l, 1), **arm(l - 1))
                 return True
-            ops.gemm_nn(dH, W, out=dZ, n_rows=n, **self._wp(l, 1))
+            ops.gemm_nn(dH, W, out=dZ, n_rows=n, **self._wp(l, 1), **self._scales(l, 1))
             return False
 
         for l in range(11, -1, -1):
@@ -548,8 +542,7 @@ class GcnEngine:
             dW = L.view(grads, "conv%d.lin.weight" % i, true_shape=False)
             Y, bn4, c10 = self.Y[l], self.bn4[l], self.c10s[l]
             if not have_sums:                                    # else: produced by the SpMM that wrote dZ
-                arm(l)
-                ops.bn_bwd_reduce(dZ, Y, bn4, sums2=self.sums, n_rows=n)
+                ops.bn_bwd_reduce(dZ, Y, bn4, sums2=self.sums, n_rows=n, **arm(l))
             have_sums = False
             yield comm.start_all_reduce(self.sums[: 2 * co])
             if not tail:
@@ -558,11 +551,10 @@ class GcnEngine:
             if self.fuse_bnbwd[l]:
                 # dY is never written: the two GEMMs that consume it rebuild it from (dZ, Y) on their operand loads
                 kp, dP = take(ci)
-                self._scales(l, 1)
-                ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n, **self._wp(l, 1))
+                ops.gemm_nn_bnbwd(dZ, Y, W, bn4, c10, out=dP, n_rows=n, **self._wp(l, 1), **self._scales(l, 1))
                 # after the dgrad GEMM: two panel GEMMs cannot share a CU (LDS), the wgrad's partners are the SpMM and
                 # the BatchNorm passes that follow
-                wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n), kz)
+                wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n, **self._scales(l, 1, 0)), kz)
                 release(kz)
                 yield comm.start_halo(dP, n)
                 kz, dZ = take(ci)
@@ -576,13 +568,12 @@ class GcnEngine:
                 release(kz)
                 Xp, pro = self.Y[l - 1], (self.bn4[l - 1][0], self.bn4[l - 1][1])
                 kz, dZ = take(ci)
-                self._scales(l, 1)
                 have_sums = dgrad_to_dz(dH, W, dZ, l)
-                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
+                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n, **self._scales(l, 1, 0)), kh)
                 release(kh)
                 continue
             if l == 0 and self.fuse_bnbwd0:
-                wgrad(0, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[0], bn4, c10, out=dW, n_rows=n), kz)
+                wgrad(0, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[0], bn4, c10, out=dW, n_rows=n, **self._scales(0, 1, 0)), kz)
                 release(kz)
                 continue
             ky, dY = take(co)
@@ -595,9 +586,8 @@ class GcnEngine:
             if self.agg_first[l]:
                 if l > 0:
                     kp, dP = take(ci)
-                    self._scales(l, 1)
-                    ops.gemm_nn(dY, W, out=dP, n_rows=n, **self._wp(l, 1))
-                wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n), ky)
+                    ops.gemm_nn(dY, W, out=dP, n_rows=n, **self._wp(l, 1), **self._scales(l, 1))
+                wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n, **self._scales(l, 1, 0)), ky)
                 if l > 0:
                     release(ky)
                     yield comm.start_halo(dP, n)
@@ -613,9 +603,8 @@ class GcnEngine:
                 release(ky)
                 if l > 0:
                     kz, dZ = take(ci)
-                    self._scales(l, 1)
                     have_sums = dgrad_to_dz(dH, W, dZ, l)
-                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n), kh)
+                wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n, **self._scales(l, 1, 0)), kh)
                 release(kh)
         join()                                                   # the gradients are complete when this pass returns
         if self._f16:

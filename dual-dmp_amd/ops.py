@@ -105,6 +105,13 @@ def copy_probe(src, dst, mode=0):
     check(_lib.lib().ddmp_copy_probe(_p(src), _p(dst), nbytes, int(mode), _stream()), "ddmp_copy_probe")
 
 
+def copy_probe_rows(src, dst):
+    """The copy in the gather's access pattern (64-row chunks, one 128-byte slab at a time) of a 2-D row-major tensor."""
+    assert src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous() and src.dim() == 2 and dst.shape == src.shape
+    check(_lib.lib().ddmp_copy_probe_rows(_p(src), _p(dst), src.shape[0], src.shape[1] * src.element_size(), _stream()),
+          "ddmp_copy_probe_rows")
+
+
 def set_gemm_mode(mode: int):
     """6 = bf16x6 split MFMA (f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA; 13 = f16x3 split MFMA
     in the row-panel kernels (f32-class accuracy, scaled operands: see gemm_next_scales), bf16x6 elsewhere."""
@@ -133,9 +140,71 @@ def gemm_forget_planes(planes=None):
     _lib.lib().ddmp_gemm_forget_planes(_p(planes))
 
 
+# ---------------------------------------------------------------------------------------- per-call options (ABI 3)
+class _Opts(ctypes.Structure):
+    """``ddmp_opts`` of include/ddmp_hip.h."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("bn_n_total", ctypes.c_double),
+                ("bn_C", ctypes.c_int32), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float), ("prime", ctypes.c_int32),
+                ("bn_in", ctypes.c_void_p * 3), ("bn_out", ctypes.c_void_p * 6), ("slot_a", ctypes.c_void_p),
+                ("slot_b", ctypes.c_void_p)]
+
+
+OPT_BN_FWD, OPT_BN_BWD, OPT_SCALES, OPT_PREPARED = 1, 2, 4, 8
+
+
+class BnFwd:
+    """``bn=`` of a statistics-producing call (bn_stats / gemm_nt_stats / spmm_stats): the second stage of that call's
+    reduction also writes what bn_prepare would (out4 rows = scale, shift, mean, rstd; running statistics updated) -- one
+    launch less, bitwise the same coefficients.  Explicit per-call option (DDMP_OPT_BN_FWD)."""
+    flag = OPT_BN_FWD
+
+    def __init__(self, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
+        rm, rv = (None, None) if running is None else running
+        self.n_total, self.C, self.eps, self.momentum = float(n_total), gamma.numel(), eps, momentum
+        self.ins = (gamma, beta, None)
+        self.outs = (out4[0], out4[1], out4[2], out4[3], rm, rv)
+
+
+class BnBwd:
+    """``bn=`` of a call that produces the BatchNorm-backward reductions (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred): its
+    second stage also writes what bn_bwd_prepare would (dgamma, dbeta, c10 rows = c1, c0).  DDMP_OPT_BN_BWD."""
+    flag = OPT_BN_BWD
+
+    def __init__(self, n_total, bn4, dgamma, dbeta, c10):
+        self.n_total, self.C, self.eps, self.momentum = float(n_total), dgamma.numel(), 0.0, 0.0
+        self.ins = (bn4[0], bn4[2], bn4[3])
+        self.outs = (dgamma, dbeta, c10[0], c10[1], None, None)
+
+
+def _mk_opts(bn=None, scales=None, prepared=False):
+    """-> (address | None, keep-alive) of the ddmp_opts block of ONE call.  scales = (slot_a, slot_b | None, prime)."""
+    if bn is None and scales is None and not prepared:
+        return None, None
+    o = _Opts()
+    o.struct_size = ctypes.sizeof(_Opts)
+    flags = 0
+    if bn is not None:
+        flags |= bn.flag
+        o.bn_n_total, o.bn_C, o.bn_eps, o.bn_momentum = bn.n_total, bn.C, bn.eps, bn.momentum
+        for i, t in enumerate(bn.ins):
+            o.bn_in[i] = None if t is None else t.data_ptr()
+        for i, t in enumerate(bn.outs):
+            o.bn_out[i] = None if t is None else t.data_ptr()
+    if scales is not None:
+        a, b, prime = scales
+        flags |= OPT_SCALES
+        o.slot_a = None if a is None else a.data_ptr()
+        o.slot_b = None if b is None else b.data_ptr()
+        o.prime = int(bool(prime))
+    if prepared:
+        flags |= OPT_PREPARED
+    o.flags = flags
+    return ctypes.c_void_p(ctypes.addressof(o)), (o, bn, scales)
+
+
 def gemm_next_scales(slot_a, slot_b=None, prime=False):
-    """f16 split modes: name the scale slots (float32 [4] device tensors, persistent) of the operands of the NEXT gemm_*
-    call -- slot_a: the row operand (a / dz / g), slot_b: z of the tn forms.  Without this the library measures every
+    """DEPRECATED (ABI 2; the engines pass ``scales=`` to the call itself).  f16 split modes: name the scale slots (float32 [4]
+    device tensors, persistent) of the operands of the NEXT gemm_* call -- slot_a: the row operand (a / dz / g), slot_b: z of the tn forms.  Without this the library measures every
     operand's absolute maximum in a pre-pass; with it the kernels use the maximum the previous iteration's kernels
     recorded (gemm_scales_roll), ``prime`` forces the measurement (first iteration)."""
     check(_lib.lib().ddmp_gemm_next_scales(_p(slot_a), _p(slot_b), int(bool(prime))), "ddmp_gemm_next_scales")
@@ -325,7 +394,7 @@ def spmm_stats_supported(C, dtype=torch.float32):
     return dtype == torch.float32 and bool(_lib.lib().ddmp_spmm_stats_supported(int(C)))
 
 
-def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE):
+def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE, bn=None):
     """out = spmm(g, x) (+bias, prologue) and sums (float64 [2C]) = bn_stats(out) from the same kernel: the statistics are
     summed around ``ref`` (float32 [C], close to the column means -- the previous iteration's batch means; zeros are valid)
     in float32 over 16 rows at a time, in float64 from there on (ddmp_spmm_stats)."""
@@ -338,13 +407,14 @@ def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE):
     es = x.element_size()
     alg = float(es) * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
-        st = L.ddmp_spmm_stats(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
-                               _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(bn)
+        st = L.ddmp_spmm_stats_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
+                                 _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_spmm_stats")
     return out
 
 
-def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
+def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE, bn=None):
     """out = spmm(g, x) (a gradient dZ) and sums2 = bn_bwd_reduce(out, yp, bn4) from the same kernel."""
     x, ldx = _mat(x, "x")
     out, ldy = _mat(out, "out", x)
@@ -354,8 +424,9 @@ def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE):
     ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), x.device)
     alg = 3.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
-        st = L.ddmp_spmm_bnred(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
-                               _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(bn)
+        st = L.ddmp_spmm_bnred_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
+                                 _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_spmm_bnred")
     return out
 
@@ -418,16 +489,16 @@ def gemm_rows_workspace_bytes(K, M):
 
 
 def _wws(wplanes, nbytes, device):
-    """The weight-plane workspace of a GEMM call: the caller's prepared buffer (announced to the library) or scratch."""
+    """The weight-plane workspace of a GEMM call -> (buffer, prepared): the caller's prepared buffer (the call is then given
+    DDMP_OPT_PREPARED) or scratch."""
     if wplanes is not None:
         if wplanes.numel() < nbytes:
             raise DdmpError("wplanes: %d bytes, the product needs %d" % (wplanes.numel(), nbytes))
-        _lib.lib().ddmp_gemm_next_prepared()
-        return wplanes
-    return Workspace.get(nbytes, device)
+        return wplanes, True
+    return Workspace.get(nbytes, device), False
 
 
-def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None):
+def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None, scales=None):
     """out[n,M] = f(a[n,K]) @ w[M,K]^T (+bias)."""
     a, lda = _mat(a, "a")
     w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
@@ -440,16 +511,17 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplan
     out, ldy = _mat(out, "out", a)
     ps, psh = (None, None) if pro is None else pro
     L = _lib.lib()
-    ws = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nt(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
-                            slope, _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(None, scales, prep)
+        st = L.ddmp_gemm_nt_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
+                              slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nt")
     return out
 
 
-def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None):
+def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplanes=None, scales=None, bn=None):
     """gemm_nt that also fills ``sums`` (float64 [2M]) with the column sums of out and out^2 (= bn_stats(out)):
     produced in the row-panel kernel's epilogue where that kernel runs, by a separate pass otherwise."""
     if a.dtype == torch.bfloat16:
@@ -469,12 +541,13 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
             sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, M)
             ws = Workspace.get(nb + sb, a.device)
             with _timed("gemm_nt", (K, M), 2.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-                st = L.ddmp_gemm_nt_stats_bf16(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
-                                               _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream())
+                o, keep = _mk_opts(bn)
+                st = L.ddmp_gemm_nt_stats_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
+                                                 _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream(), o)
             check(st, "ddmp_gemm_nt_stats_bf16")
             return out
         out = gemm_nt(a, w, out=out, bias=bias, pro=pro, slope=slope, n_rows=n_rows)
-        bn_stats(out, sums=sums, n_rows=n_rows)
+        bn_stats(out, sums=sums, n_rows=n_rows, bn=bn)
         return out
     a, lda = _mat(a, "a")
     w, ldw = _mat(w, "w")
@@ -490,16 +563,17 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, M)
     ws = Workspace.get(nb + sb, a.device)
-    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
+    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
     with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nt_stats_f32(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
-                                      _p(sums), _p(wp), nb if wplanes is None else wp.numel(), ws.data_ptr() + nb,
-                                      ws.numel() - nb, _stream())
+        o, keep = _mk_opts(bn, scales, wplanes is not None)
+        st = L.ddmp_gemm_nt_stats_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
+                                        _p(sums), _p(wp), nb if wplanes is None else wp.numel(), ws.data_ptr() + nb,
+                                        ws.numel() - nb, _stream(), o)
     check(st, "ddmp_gemm_nt_stats_f32")
     return out
 
 
-def gemm_nn(a, w, out=None, n_rows=None, wplanes=None):
+def gemm_nn(a, w, out=None, n_rows=None, wplanes=None, scales=None):
     """out[n,K] = a[n,M] @ w[M,K]."""
     a, lda = _mat(a, "a")
     w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
@@ -511,10 +585,11 @@ def gemm_nn(a, w, out=None, n_rows=None, wplanes=None):
         out = torch.empty((n, K), dtype=a.dtype, device=a.device)
     out, ldy = _mat(out, "out", a)
     L = _lib.lib()
-    ws = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
+    ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nn(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(None, scales, prep)
+        st = L.ddmp_gemm_nn_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nn")
     return out
 
@@ -524,7 +599,7 @@ def gemm_nn_bnred_supported(M, K, n_rows, dtype=torch.float32):
     return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_nn_bnred_supported(int(M), int(K), int(n_rows)))
 
 
-def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplanes=None):
+def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplanes=None, scales=None, bn=None):
     """out[n,K] = a[n,M] @ w[M,K] AND sums (float64 [2K]) = bn_bwd_reduce(out, yp, bn4): the BatchNorm-backward column
     reductions of `out` as the gradient behind the previous layer's BatchNorm+LeakyReLU (yp: that layer's conv output),
     from the GEMM epilogue -- one read of yp instead of a pass over out and yp."""
@@ -540,16 +615,17 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
     ws = Workspace.get(nb + sb, a.device)
-    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)
+    wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
     with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nn_bnred_f32(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
-                                      _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(wp), nb if wplanes is None else wp.numel(),
-                                      ws.data_ptr() + nb, ws.numel() - nb, _stream())
+        o, keep = _mk_opts(bn, scales, wplanes is not None)
+        st = L.ddmp_gemm_nn_bnred_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
+                                        _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(wp), nb if wplanes is None else wp.numel(),
+                                        ws.data_ptr() + nb, ws.numel() - nb, _stream(), o)
     check(st, "ddmp_gemm_nn_bnred_f32")
     return out
 
 
-def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
+def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None, scales=None):
     """out[M,K] = g[n,M]^T @ f(z[n,K])  (weight gradient)."""
     g, ldg = _mat(g, "g")
     z, ldz = _mat(z, "z", g)
@@ -564,8 +640,9 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None):
     ps, psh = (None, None) if pro is None else pro
     es = g.element_size()
     with _timed("gemm_tn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_tn(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _dt(g), _p(ps), _p(psh), slope, _p(ws),
-                            ws.numel(), _stream())
+        o, keep = _mk_opts(None, scales)
+        st = L.ddmp_gemm_tn_o(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _dt(g), _p(ps), _p(psh), slope, _p(ws),
+                              ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_tn")
     return out
 
@@ -606,7 +683,7 @@ def to_bf16(src, dst=None):
     return dst
 
 
-def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplanes=None):
+def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplanes=None, scales=None):
     """out[n,K] = dY[n,M] @ w[M,K] with dY = BatchNorm+LeakyReLU backward of (dz, yb) computed on the operand load
     (what bn_bwd_apply would have written: a*dz*lrelu'(a*yb+b) + c1*yb + c0)."""
     if dz.dtype == torch.bfloat16:
@@ -634,15 +711,16 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplan
         out = torch.empty((n, K), dtype=torch.float32, device=dz.device)
     out, ldo = _mat(out, "out")
     L = _lib.lib()
-    ws = _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
+    ws, prep = _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
     with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_nn_bnbwd_f32(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
-                                      _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(None, scales, prep)
+        st = L.ddmp_gemm_nn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                        _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nn_bnbwd_f32")
     return out
 
 
-def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=None):
+def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=None, scales=None):
     """out[M,K] = dY^T @ f(z) with dY as in gemm_nn_bnbwd."""
     if dz.dtype == torch.bfloat16:
         dz, lddz = _mat(dz, "dz")
@@ -673,8 +751,9 @@ def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=N
     ws = Workspace.get(L.ddmp_gemm_tn_workspace_bytes(n, M, K), dz.device)
     ps, psh = (None, None) if pro is None else pro
     with _timed("gemm_tn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
-        st = L.ddmp_gemm_tn_bnbwd_f32(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
-                                      _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(None, scales)
+        st = L.ddmp_gemm_tn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
+                                        _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_tn_bnbwd_f32")
     return out
 
@@ -686,7 +765,7 @@ def _colws(n, C, device):
     return Workspace.get(need, device)
 
 
-def bn_stats(y, sums=None, n_rows=None):
+def bn_stats(y, sums=None, n_rows=None, bn=None):
     """-> float64 [2C] = (column sums, column sums of squares) of y[:n_rows]."""
     y, ldy = _mat(y, "y")
     n = y.shape[0] if n_rows is None else n_rows
@@ -695,7 +774,8 @@ def bn_stats(y, sums=None, n_rows=None):
         sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
     with _timed("bn_stats", C, float(y.element_size()) * n * C):
-        st = _lib.lib().ddmp_bn_stats(_p(y), ldy, n, C, _dt(y), _p(sums), _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(bn)
+        st = _lib.lib().ddmp_bn_stats_o(_p(y), ldy, n, C, _dt(y), _p(sums), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_bn_stats")
     return sums
 
@@ -711,7 +791,8 @@ def bn_prepare(sums, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momen
 
 
 def bn_next_prepare(n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    """Arm the NEXT statistics-producing call of this thread (bn_stats / gemm_nt_stats) so that its second stage writes
+    """DEPRECATED (ABI 2; the engines pass ``bn=BnFwd(...)`` to the call itself).  Arm the NEXT statistics-producing call of
+    this thread (bn_stats / gemm_nt_stats) so that its second stage writes
     what bn_prepare would (ddmp_bn_next_prepare: one launch less, bitwise the same coefficients)."""
     C = gamma.numel()
     rm, rv = (None, None) if running is None else running
@@ -720,7 +801,8 @@ def bn_next_prepare(n_total, gamma, beta, out4, running=None, eps=BN_EPS, moment
 
 
 def bn_next_bwd_prepare(n_total, bn4, dgamma, dbeta, c10):
-    """Arm the NEXT call that produces the BatchNorm-backward reductions (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred) so
+    """DEPRECATED (ABI 2; the engines pass ``bn=BnBwd(...)``).  Arm the NEXT call that produces the BatchNorm-backward
+    reductions (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred) so
     that its second stage writes what bn_bwd_prepare would."""
     C = dgamma.numel()
     check(_lib.lib().ddmp_bn_next_bwd_prepare(float(n_total), C, _p(bn4[0]), _p(bn4[2]), _p(bn4[3]), _p(dgamma), _p(dbeta),
@@ -738,7 +820,7 @@ def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):
     return out
 
 
-def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None):
+def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None, bn=None):
     dz, lddz = _mat(dz, "dz")
     y, ldy = _mat(y, "y", dz)
     n = y.shape[0] if n_rows is None else n_rows
@@ -747,8 +829,9 @@ def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None):
         sums2 = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
     with _timed("bn_bwd_reduce", C, 2.0 * y.element_size() * n * C):
-        st = _lib.lib().ddmp_bn_bwd_reduce(_p(dz), lddz, _p(y), ldy, n, C, _dt(y), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
-                                           _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream())
+        o, keep = _mk_opts(bn)
+        st = _lib.lib().ddmp_bn_bwd_reduce_o(_p(dz), lddz, _p(y), ldy, n, C, _dt(y), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
+                                             _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_bn_bwd_reduce")
     return sums2
 

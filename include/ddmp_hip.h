@@ -34,7 +34,8 @@ extern "C" {
 #define DDMP_ENOMEM (-3)      /* host allocation failed */
 #define DDMP_EWORKSPACE (-4)  /* caller workspace too small */
 
-#define DDMP_ABI_VERSION 2      /* 2 (round 4): rules for the "armed for the next call" state + ddmp_next_pending / ddmp_next_cancel /
+#define DDMP_ABI_VERSION 3      /* 3 (round 5): per-call options (ddmp_opts, the *_o entry points) replace the armed state;
+                                   2 (round 4): rules for the "armed for the next call" state + ddmp_next_pending / ddmp_next_cancel /
                                    ddmp_gemm_forget_planes; additions only otherwise (the *_bf16 and dtype-tagged entry points) */
 
 typedef struct ddmp_graph ddmp_graph;
@@ -496,6 +497,9 @@ int ddmp_trace_marker(ddmp_stream stream);
 /* measurement aid (bench.py's copy yardstick): a streaming device copy of `bytes` (multiple of 16, both pointers 16-byte
  * aligned) written like the library's HBM-bound kernels; mode 0 plain, 1 nontemporal loads / stores */
 int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_stream stream);
+/* ... and the same copy in the gather's access pattern: 64-row chunks of a row-major [n_rows, row_bytes] matrix walked one
+ * 128-byte slab at a time (row_bytes a multiple of 128): the ceiling of that pattern, whatever the graph */
+int ddmp_copy_probe_rows(const void* src, void* dst, int64_t n_rows, int row_bytes, ddmp_stream stream);
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
 
@@ -536,6 +540,75 @@ int ddmp_head_bwd(const void* Y, int64_t ldy, int64_t n_rows, int dtype, const f
                   float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
                   const float* dout, void* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
                   void* workspace, size_t workspace_bytes, ddmp_stream stream);
+
+
+/* ------------------------------------------------------------------ ABI 3: per-call options instead of "armed" state
+ * Everything the ddmp_*_next_* calls used to attach to "the next call of this host thread" is an explicit, nullable last
+ * argument of the call itself: `name_o(<the arguments of name>, const ddmp_opts* opts)`.  The options apply to THAT call and
+ * to nothing else (whatever it returns); opts == NULL is the plain call.  The arming calls above stay for one more round as
+ * deprecated wrappers (they fill the same per-thread record the _o forms set and clear around their call).
+ *   DDMP_OPT_BN_FWD   the call's float64 [2C] reduction (sum y, sum y^2) also yields what ddmp_bn_prepare_f32 would write:
+ *                     bn_in = {gamma, beta}, bn_out = {scale, shift, mean, rstd, running_mean | NULL, running_var | NULL}
+ *   DDMP_OPT_BN_BWD   ... (sum g, sum g yhat) also yields what ddmp_bn_bwd_prepare_f32 would write:
+ *                     bn_in = {scale, mean, rstd}, bn_out = {dgamma, dbeta, c1, c0}
+ *                     (bn_C must be the reduction's width, bn_n_total the row count of the whole batch)
+ *   DDMP_OPT_SCALES   f16x3 GEMM mode: persistent scale slots of the operands (slot_a: the row operand A / dZ / G, slot_b:
+ *                     Z of the tn forms, either may be NULL); prime != 0: measure now (first iteration)
+ *   DDMP_OPT_PREPARED `workspace` holds weight planes written by ddmp_gemm_prepare_weights for exactly this product */
+#define DDMP_OPT_BN_FWD 1u
+#define DDMP_OPT_BN_BWD 2u
+#define DDMP_OPT_SCALES 4u
+#define DDMP_OPT_PREPARED 8u
+typedef struct ddmp_opts {
+    uint32_t struct_size; /* sizeof(ddmp_opts) of the caller's header */
+    uint32_t flags;       /* DDMP_OPT_* */
+    double bn_n_total;
+    int32_t bn_C;
+    float bn_eps, bn_momentum;
+    int32_t prime;
+    const float* bn_in[3];
+    float* bn_out[6];
+    float* slot_a;
+    float* slot_b;
+} ddmp_opts;
+int ddmp_bn_stats_o(const void* Y, int64_t ldy, int64_t n_rows, int C, int dtype, double* sums, void* workspace,
+    size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_bn_bwd_reduce_o(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t n_rows, int C, int dtype,
+    const float* scale, const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
+    void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_spmm_stats_o(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+    const float* bias, const float* pro_scale, const float* pro_shift, float slope, const float* ref, double* sums2,
+    void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_spmm_bnred_o(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
+    const void* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean, const float* rstd,
+    float slope, double* sums2, void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_nt_o(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n_rows,
+    int K, int M, int dtype, const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+    void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_nn_o(const void* A, int64_t lda, const float* W, int64_t ldw, void* Y, int64_t ldy, int64_t n_rows,
+    int M, int K, int dtype, void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_tn_o(const void* G, int64_t ldg, const void* Z, int64_t ldz, float* dW, int64_t lddw, int64_t n_rows,
+    int M, int K, int dtype, const float* pro_scale, const float* pro_shift, float slope, void* workspace,
+    size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_nt_stats_f32_o(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
+    int64_t n_rows, int K, int M, const float* bias , const float* pro_scale , const float* pro_shift , float slope,
+    double* sums2 , void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream,
+    const ddmp_opts* opts);
+int ddmp_gemm_nt_stats_bf16_o(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
+    int64_t n_rows, int K, int M, const float* bias, const float* pro_scale, const float* pro_shift, float slope,
+    double* sums2, void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream,
+    const ddmp_opts* opts);
+int ddmp_gemm_nn_bnred_f32_o(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
+    int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale, const float* shift,
+    const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
+    void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_nn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,
+    float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b, const float* c1,
+    const float* c0, float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_tn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* Z, int64_t ldz,
+    float* dW, int64_t lddw, int64_t n_rows, int M, int K, const float* a, const float* b, const float* c1,
+    const float* c0, const float* pro_scale , const float* pro_shift , float slope, void* workspace,
+    size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
 
 #ifdef __cplusplus
 }

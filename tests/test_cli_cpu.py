@@ -14,7 +14,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = _lib.lib()                       # resolves every prototype or raises
     for name in protos:
         assert hasattr(lib, name), name
-    assert lib.ddmp_abi_version() == 2
+    assert lib.ddmp_abi_version() == 3
     assert _lib.status_string(0) == "ok" and _lib.status_string(-4) == "workspace too small"
     # argument validation happens before any device work
     assert lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None) == -1
@@ -61,6 +61,43 @@ def test_armed_state_cannot_leak_past_an_error():
         _lib.check(lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None), "ddmp_spmm_f32")
     assert lib.ddmp_next_pending() == 0
     assert lib.ddmp_gemm_forget_planes(None) == 0 and lib.ddmp_gemm_forget_planes(p) == 0
+
+
+def test_per_call_options_reach_their_own_call_only():
+    """ABI 3: the *_o entry points take what used to be armed "for the next call" as an explicit ddmp_opts argument.  The
+    options apply to that call alone -- whatever it returns --, nothing armed earlier (deprecated ddmp_*_next_* calls) can reach
+    an _o call, and a malformed block is an argument error.  No device work involved (every call fails its argument checks)."""
+    from dual_dmp_amd import _lib, ops
+    lib = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.ddmp_next_cancel() == 0
+
+    class T:                                                     # a stand-in with .data_ptr() / .numel()
+        def data_ptr(self):
+            return p.value
+
+        def numel(self):
+            return 32
+    t = T()
+    o, keep = ops._mk_opts(ops.BnFwd(100.0, t, t, [t, t, t, t]), (t, None, True), True)
+    assert keep[0].flags == ops.OPT_BN_FWD | ops.OPT_SCALES | ops.OPT_PREPARED and keep[0].struct_size == ctypes.sizeof(ops._Opts)
+    # the wrapped call fails its argument checks: the options are gone afterwards
+    assert lib.ddmp_gemm_nt_stats_f32_o(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, None, 0, None, 0, None, o) == -1
+    assert lib.ddmp_next_pending() == 0
+    # state armed through the deprecated calls does not reach an _o call (and is gone after it)
+    assert lib.ddmp_gemm_next_scales(p, p, 0) == 0 and lib.ddmp_next_pending() == 2
+    assert lib.ddmp_gemm_nn_o(None, 0, None, 0, None, 0, 0, 0, 0, 0, None, 0, None, None) == -1
+    assert lib.ddmp_next_pending() == 0
+    # a block of another size / with unknown flags / with both BatchNorm directions: argument error before the call
+    keep[0].struct_size = 8
+    assert lib.ddmp_bn_stats_o(None, 0, 0, 32, 0, None, None, 0, None, o) == -1
+    keep[0].struct_size = ctypes.sizeof(ops._Opts)
+    keep[0].flags = 64
+    assert lib.ddmp_bn_stats_o(None, 0, 0, 32, 0, None, None, 0, None, o) == -1
+    keep[0].flags = ops.OPT_BN_FWD | ops.OPT_BN_BWD
+    assert lib.ddmp_bn_stats_o(None, 0, 0, 32, 0, None, None, 0, None, o) == -1
+    assert lib.ddmp_next_pending() == 0
 
 
 def test_host_csr_matches_gcn_norm(oracle):

