@@ -239,6 +239,11 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
             split_store(x, &Gs[buf][0][o], &Gs[buf][1][o]);
         }
     };
+    // (PRO: rows past the split read as 0 through the descriptor and the prologue maps them to lrelu(shift) != 0 -- harmless for
+    //  the product (their G rows ARE 0) but folded into zmax: with a Z prologue the published Z maximum is an UPPER BOUND that
+    //  may include max_k |lrelu(shift_k)| when the split's last stage is ragged; never smaller than the true maximum, so a scale
+    //  derived from it cannot overflow -- at worst it is one binade coarser.  Masking here costs 8 VALU per piece in a loop that
+    //  is issue-bound, for a bound that is already safe: not done.)
     auto store_z = [&](int buf, const Slot& sl) __attribute__((always_inline)) {
         const float4* zsrc = ZL == 2 ? sl.z : Z1;
         int co = zc4;

@@ -129,9 +129,9 @@ def next_pending() -> int:
 
 
 def next_cancel():
-    """Drop everything armed for "the next call" on this host thread.  The engines call it at the top of every forward /
-    backward pass (an exception between arming and the armed call -- in user code, in a hook -- must not attach coefficients
-    or scale slots to a later, unrelated launch); a failing ddmp call cancels by itself (_lib.check)."""
+    """Drop everything left "for the next call" on this host thread: the deprecated two-step helpers' host-side requests and
+    whatever a foreign caller armed in the library (ABI 2 calls)."""
+    _pending.bn = _pending.scales = None
     _lib.lib().ddmp_next_cancel()
 
 
@@ -176,8 +176,26 @@ class BnBwd:
         self.outs = (dgamma, dbeta, c10[0], c10[1], None, None)
 
 
-def _mk_opts(bn=None, scales=None, prepared=False):
-    """-> (address | None, keep-alive) of the ddmp_opts block of ONE call.  scales = (slot_a, slot_b | None, prime)."""
+_pending = threading.local()        # the deprecated two-step forms (bn_next_* / gemm_next_scales): kept on the HOST side only
+
+
+def _take(kind):
+    v = getattr(_pending, kind, None)
+    if v is not None:
+        setattr(_pending, kind, None)
+    return v
+
+
+def _mk_opts(bn=None, scales=None, prepared=False, want_bn=False, want_scales=False):
+    """-> (address | None, keep-alive) of the ddmp_opts block of ONE call.  scales = (slot_a, slot_b | None, prime).
+    want_bn / want_scales: this call is of the family that consumes a request left by the deprecated two-step helpers
+    (bn_next_prepare / bn_next_bwd_prepare / gemm_next_scales) -- consumed or dropped here, like the C-level armed state was."""
+    if want_bn:
+        left = _take("bn")
+        bn = bn if bn is not None else left
+    if want_scales:
+        left = _take("scales")
+        scales = scales if scales is not None else left
     if bn is None and scales is None and not prepared:
         return None, None
     o = _Opts()
@@ -203,11 +221,10 @@ def _mk_opts(bn=None, scales=None, prepared=False):
 
 
 def gemm_next_scales(slot_a, slot_b=None, prime=False):
-    """DEPRECATED (ABI 2; the engines pass ``scales=`` to the call itself).  f16 split modes: name the scale slots (float32 [4]
-    device tensors, persistent) of the operands of the NEXT gemm_* call -- slot_a: the row operand (a / dz / g), slot_b: z of the tn forms.  Without this the library measures every
-    operand's absolute maximum in a pre-pass; with it the kernels use the maximum the previous iteration's kernels
-    recorded (gemm_scales_roll), ``prime`` forces the measurement (first iteration)."""
-    check(_lib.lib().ddmp_gemm_next_scales(_p(slot_a), _p(slot_b), int(bool(prime))), "ddmp_gemm_next_scales")
+    """DEPRECATED two-step form (the engines pass ``scales=`` to the call itself): name the scale slots of the operands of the
+    NEXT gemm_* call of this thread.  Since ABI 3 this is remembered on the HOST side and handed to that call as its explicit
+    per-call option; nothing is armed in the library."""
+    _pending.scales = (slot_a, slot_b, bool(prime))
 
 
 def gemm_scales_roll(slots):
@@ -407,7 +424,7 @@ def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE, bn
     es = x.element_size()
     alg = float(es) * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
-        o, keep = _mk_opts(bn)
+        o, keep = _mk_opts(bn, want_bn=True)
         st = L.ddmp_spmm_stats_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
                                  _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_spmm_stats")
@@ -424,7 +441,7 @@ def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE, bn=None):
     ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), x.device)
     alg = 3.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
-        o, keep = _mk_opts(bn)
+        o, keep = _mk_opts(bn, want_bn=True)
         st = L.ddmp_spmm_bnred_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                  _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_spmm_bnred")
@@ -514,7 +531,7 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplan
     ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(None, scales, prep)
+        o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nt_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
                               slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nt")
@@ -541,7 +558,7 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
             sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, M)
             ws = Workspace.get(nb + sb, a.device)
             with _timed("gemm_nt", (K, M), 2.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-                o, keep = _mk_opts(bn)
+                o, keep = _mk_opts(bn, want_bn=True)
                 st = L.ddmp_gemm_nt_stats_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
                                                  _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream(), o)
             check(st, "ddmp_gemm_nt_stats_bf16")
@@ -565,7 +582,7 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
     ws = Workspace.get(nb + sb, a.device)
     wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
     with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(bn, scales, wplanes is not None)
+        o, keep = _mk_opts(bn, scales, wplanes is not None, want_bn=True, want_scales=True)
         st = L.ddmp_gemm_nt_stats_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
                                         _p(sums), _p(wp), nb if wplanes is None else wp.numel(), ws.data_ptr() + nb,
                                         ws.numel() - nb, _stream(), o)
@@ -588,7 +605,7 @@ def gemm_nn(a, w, out=None, n_rows=None, wplanes=None, scales=None):
     ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
     with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(None, scales, prep)
+        o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nn_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nn")
     return out
@@ -617,7 +634,7 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
     ws = Workspace.get(nb + sb, a.device)
     wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
     with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(bn, scales, wplanes is not None)
+        o, keep = _mk_opts(bn, scales, wplanes is not None, want_bn=True, want_scales=True)
         st = L.ddmp_gemm_nn_bnred_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                         _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(wp), nb if wplanes is None else wp.numel(),
                                         ws.data_ptr() + nb, ws.numel() - nb, _stream(), o)
@@ -640,7 +657,7 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None, scales=None):
     ps, psh = (None, None) if pro is None else pro
     es = g.element_size()
     with _timed("gemm_tn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(None, scales)
+        o, keep = _mk_opts(None, scales, want_scales=True)
         st = L.ddmp_gemm_tn_o(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _dt(g), _p(ps), _p(psh), slope, _p(ws),
                               ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_tn")
@@ -713,7 +730,7 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplan
     L = _lib.lib()
     ws, prep = _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
     with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(None, scales, prep)
+        o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                         _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nn_bnbwd_f32")
@@ -751,7 +768,7 @@ def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=N
     ws = Workspace.get(L.ddmp_gemm_tn_workspace_bytes(n, M, K), dz.device)
     ps, psh = (None, None) if pro is None else pro
     with _timed("gemm_tn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
-        o, keep = _mk_opts(None, scales)
+        o, keep = _mk_opts(None, scales, want_scales=True)
         st = L.ddmp_gemm_tn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                         _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_tn_bnbwd_f32")
@@ -774,7 +791,7 @@ def bn_stats(y, sums=None, n_rows=None, bn=None):
         sums = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
     with _timed("bn_stats", C, float(y.element_size()) * n * C):
-        o, keep = _mk_opts(bn)
+        o, keep = _mk_opts(bn, want_bn=True)
         st = _lib.lib().ddmp_bn_stats_o(_p(y), ldy, n, C, _dt(y), _p(sums), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_bn_stats")
     return sums
@@ -791,22 +808,14 @@ def bn_prepare(sums, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momen
 
 
 def bn_next_prepare(n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    """DEPRECATED (ABI 2; the engines pass ``bn=BnFwd(...)`` to the call itself).  Arm the NEXT statistics-producing call of
-    this thread (bn_stats / gemm_nt_stats) so that its second stage writes
-    what bn_prepare would (ddmp_bn_next_prepare: one launch less, bitwise the same coefficients)."""
-    C = gamma.numel()
-    rm, rv = (None, None) if running is None else running
-    check(_lib.lib().ddmp_bn_next_prepare(float(n_total), C, _p(gamma), _p(beta), eps, momentum, _p(out4[0]), _p(out4[1]),
-                                          _p(out4[2]), _p(out4[3]), _p(rm), _p(rv)), "ddmp_bn_next_prepare")
+    """DEPRECATED two-step form of ``bn=BnFwd(...)``: remembered on the HOST side for the next statistics-producing call of this
+    thread (bn_stats / gemm_nt_stats / spmm_stats), which receives it as its explicit per-call option."""
+    _pending.bn = BnFwd(n_total, gamma, beta, out4, running, eps, momentum)
 
 
 def bn_next_bwd_prepare(n_total, bn4, dgamma, dbeta, c10):
-    """DEPRECATED (ABI 2; the engines pass ``bn=BnBwd(...)``).  Arm the NEXT call that produces the BatchNorm-backward
-    reductions (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred) so
-    that its second stage writes what bn_bwd_prepare would."""
-    C = dgamma.numel()
-    check(_lib.lib().ddmp_bn_next_bwd_prepare(float(n_total), C, _p(bn4[0]), _p(bn4[2]), _p(bn4[3]), _p(dgamma), _p(dbeta),
-                                              _p(c10[0]), _p(c10[1])), "ddmp_bn_next_bwd_prepare")
+    """DEPRECATED two-step form of ``bn=BnBwd(...)`` (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred)."""
+    _pending.bn = BnBwd(n_total, bn4, dgamma, dbeta, c10)
 
 
 def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):
@@ -829,7 +838,7 @@ def bn_bwd_reduce(dz, y, bn4, sums2=None, slope=SLOPE, n_rows=None, bn=None):
         sums2 = torch.empty(2 * C, dtype=torch.float64, device=y.device)
     ws = _colws(n, C, y.device)
     with _timed("bn_bwd_reduce", C, 2.0 * y.element_size() * n * C):
-        o, keep = _mk_opts(bn)
+        o, keep = _mk_opts(bn, want_bn=True)
         st = _lib.lib().ddmp_bn_bwd_reduce_o(_p(dz), lddz, _p(y), ldy, n, C, _dt(y), _p(bn4[0]), _p(bn4[1]), _p(bn4[2]),
                                              _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_bn_bwd_reduce")

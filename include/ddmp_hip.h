@@ -173,7 +173,9 @@ int ddmp_bn_next_cancel(void);
  * ddmp_gemm_next_prepared (bit 2) -- as a bit mask, and a cancel for all of it.  Rules of the armed state (ABI 2): it is
  * consumed or DROPPED by the next entry point of its family whether that call succeeds or returns an error; a BatchNorm
  * request is only attached to a reduction of its own width C and only when the call has a sums buffer; a host mirror that
- * arms and calls in two steps cancels in its error path (dual-dmp_amd/ops.py: `armed`). */
+ * arms and calls in two steps cancels in its error path (dual-dmp_amd/_lib.py: `check`).
+ * DEPRECATED since ABI 3: the *_o entry points at the end of this header take the same requests as an explicit per-call
+ * ddmp_opts argument; dual-dmp_amd/engine.py no longer arms anything. */
 int ddmp_next_pending(void);
 int ddmp_next_cancel(void);
 /* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias; dbias_sums NULL: dY only -- behind
