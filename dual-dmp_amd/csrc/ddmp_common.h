@@ -133,9 +133,6 @@ struct ddmp_graph {
     int32_t* rowptr;    // device [n_rows + 1]
     int32_t* col;       // device [nnz]
     float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
-    float* wcol;        // device [nnz]      dinv[col[e]] per entry (round 5: the gather kernels stage col and weight with two
-                        //                   independent coalesced loads instead of a dependent gather of dinv -- one global
-                        //                   round trip less in a chunk's set-up, which is what bounds the narrow widths)
     int max_row_nnz;
     // LDS-patch gather (spmm_patch.hip).  Per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR
     // entry, the index of its column in that list.  Selection is PER CHUNK: a chunk whose patch does not fit the kernel's

@@ -147,12 +147,6 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
     if (g->nnz > 0 &&
         (e = hipMemcpy(g->col, col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
-    {
-        std::vector<float> wc((size_t)std::max<int64_t>(g->nnz, 1));
-        for (int64_t i = 0; i < g->nnz; ++i) wc[(size_t)i] = dinv[col[i]];
-        if ((e = hipMalloc((void**)&g->wcol, sizeof(float) * wc.size())) != hipSuccess) goto fail;
-        if ((e = hipMemcpy(g->wcol, wc.data(), sizeof(float) * wc.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
-    }
     {   // patch tables (see ddmp_graph): skipped when the rows of a chunk fan out too far (unordered numbering)
         const int64_t n_chunks = (n_rows + ddmp::kChunkRows - 1) / ddmp::kChunkRows;
         // by default from 64k rows for graphs with at most 12 entries per row ON AVERAGE (mesh graphs: 4 and ~7; the LDS
@@ -269,7 +263,6 @@ extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
     if (g->rowptr) (void)hipFree(g->rowptr);
     if (g->col) (void)hipFree(g->col);
     if (g->dinv) (void)hipFree(g->dinv);
-    if (g->wcol) (void)hipFree(g->wcol);
     if (g->pl_ptr) (void)hipFree(g->pl_ptr);
     if (g->pl_col) (void)hipFree(g->pl_col);
     if (g->lcol) (void)hipFree(g->lcol);

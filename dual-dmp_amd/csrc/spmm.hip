@@ -367,7 +367,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
     const int n = (int)g->n_rows;
     if (chunk_list) {
         if (n_list <= 0) return DDMP_OK;
-        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->wcol, X, ldx,
+        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
                            Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
         LAUNCH_TRY();
         return DDMP_OK;
@@ -383,7 +383,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         const int per = (n_slabs + want - 1) / want;
         groups = (n_slabs + per - 1) / per;
     }
-    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->wcol, X, ldx,
+    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
                        Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, (const int*)nullptr, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -74,7 +74,7 @@ template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f
 // slots exceed the LDS array reads its entries from global memory), `chunk_list` = the LDS-patch kernel's heavy chunks.
 template <int VW, int LANES, int U, bool PRO, int RED, bool BWD, bool LEAN>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv, const float* __restrict__ wcol,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope, int chunks_per_xcd, int n_chunks, const int* __restrict__ chunk_list, BnRedB red, BnBwdGatherB bwd) {
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
             const int qo = __shfl(qoff_l, lr, 64), nq = __shfl(nq_l, lr, 64), nn = __shfl(nn_l, lr, 64);
             const int rb = s_rowptr[min(lr, nr)];
             for (int k = tid & 3; k < 4 * nq; k += 4) {          // padding: the row's last entry again, weight 0
-                const int e = rb + min(k, nn - 1);               // (col and weight: two independent loads)
-                s_ent[4 * qo + k] = make_uint2((unsigned)col[e] * ld16, k < nn ? __float_as_uint(wcol[e]) : 0u);
+                const int c = col[rb + min(k, nn - 1)];
+                s_ent[4 * qo + k] = make_uint2((unsigned)c * ld16, k < nn ? __float_as_uint(dinv[c]) : 0u);
             }
         }
     } else {
@@ -362,10 +362,10 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
     const bool lean = lean_on && lean_b16_ok(g, ldx) && (!BWD || bwd.ldyb == ldx);
     if (lean)
         hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, true>), grid, dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, g->wcol, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     else
         hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, false>), grid, dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, g->wcol, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
+                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -77,7 +77,7 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 template <typename T, int KD, bool PRO, int RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-    const float* __restrict__ dinv, const float* __restrict__ wcol, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
+    const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
     const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
     int chunks_per_xcd, int n_chunks, RedArgs red) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (dispatcher: max_row_nnz <= 16)
     for (int t = tid; t < ne; t += 256) {
         s_lc[t] = lcol[e0 + t];
-        s_w[t] = wcol[e0 + t];
+        s_w[t] = dinv[col[e0 + t]];
     }
     __syncthreads();                                             // (plain loads above: all waited for by now)
     int rows[2];                                                 // this lane's two rows (local indices; clamped on a ragged chunk)
@@ -403,7 +403,7 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
         }
         attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->wcol, g->pl_ptr, g->pl_col, X,
+    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->pl_ptr, g->pl_col, X,
                        ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
     LAUNCH_TRY();
     return DDMP_OK;
