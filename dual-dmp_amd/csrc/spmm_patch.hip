@@ -465,13 +465,13 @@ int patch_mode() {
 
 }  // namespace
 
-// DDMP_SPMM_PATCH_FORMS (A/B, default 7): bit 0 the prologue form at C >= 512, bit 1 the fused BatchNorm-backward reduction, bit 2
-// the fused statistics form on the LDS-patch kernel (all from C = 256) -- round 5, measured with the RCB numbering (smaller
+// DDMP_SPMM_PATCH_FORMS (A/B, default 15): bit 0 the prologue form at C >= 512, bit 1 the fused BatchNorm-backward reduction, bit 2
+// the fused statistics form on the LDS-patch kernel (all from C = 256), bit 3 bfloat16 features on it (plain, prologue, statistics) -- round 5, measured with the RCB numbering (smaller
 // patches: KD = 5 instead of 6, one more workgroup per CU), 1M faces, us per launch patch | lean (profiles/r05_gather_forms.txt):
 //   prologue C = 512 face 812 | 935, vertex 498 | 627;  reduction C = 512 face 1246 | 1284, vertex 707 | 747, C = 256 face
 //   639 | 646, vertex 370 | 394;  statistics C = 512 face 857 | 937, vertex 505 | 616, C = 256 face 432 | 469, vertex 264 | 308
 int patch_forms() {
-    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_FORMS"); return e ? atoi(e) : 7; }();
+    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_FORMS"); return e ? atoi(e) : 15; }();
     return v;
 }
 
@@ -483,7 +483,11 @@ extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, i
     if (patch_mode() == 3) {
         // measured selection (by_patch's note, patch_forms): float32, C >= 256; row lengths are not a condition since round 5
         // (DDMP_SPMM_PATCH_MAXNNZ=n keeps the A/B switch "graphs with longer rows stay lean")
-        if (dtype != DDMP_F32 || g->max_row_nnz > patch_max_nnz() || C < 256) return 0;
+        if (g->max_row_nnz > patch_max_nnz() || C < 256) return 0;
+        // bfloat16 features (round 5, 1M faces, RCB numbering, us per launch patch | slab kernel): plain C = 512 face 420 | 457,
+        // vertex 251 | 311; prologue face 434 | 550, vertex 414 | 428; statistics face 546 | 617, vertex 377 | 425 (C = 256 alike);
+        // the fused reduction LOSES there (face 819 | 730, vertex 493 | 448) and stays on the slab kernel
+        if (dtype != DDMP_F32 && (has_red == 1 || !(patch_forms() & 8))) return 0;
         if (has_red == 1 && !(patch_forms() & 2)) return 0;
         if (has_red == 2 && !(patch_forms() & 4)) return 0;
         if (has_pro && C >= 512 && !(patch_forms() & 1)) return 0;

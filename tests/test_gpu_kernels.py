@@ -107,7 +107,8 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         if os.environ.get("DDMP_SPMM_PATCH") is None and os.environ.get("DDMP_SPMM_PATCH_FORMS") is None:
             # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256
             assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
-            assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 1, 2) == 1    # bf16
             assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 2) == 1
         # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
         src = torch.cat([ei[0], torch.arange(n)])

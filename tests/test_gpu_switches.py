@@ -38,6 +38,7 @@ SWITCHES = [
     {"DDMP_EQUAL_WIDTH": "transform"},
 ]
 BF16_SWITCHES = [
+    {"DDMP_SPMM_PATCH_FORMS": "7"},            # bf16 features stay off the LDS-patch gather (round-4 selection)
     {"DDMP_BF16_SPMM_BNRED": "0"},             # backward reductions as separate passes
     {"DDMP_BF16_FUSE": "0"},                   # no BatchNorm backward on the GEMM operand loads
     {"DDMP_TN_DMA": "0"},
