@@ -1,4 +1,4 @@
-"""Workload for counter passes on the gather: 3 launches each of the plain SpMM (C = 512, Morton order) on the face graph
+"""Workload for counter passes on the gather: 3 launches each of the plain SpMM (C = 512, RCB order: the LDS-patch kernel) on the face graph
 (1M rows, 4 entries per row) and on the vertex graph (0.5M rows, 7 entries per row) of the bench torus.
   rocprofv3 --pmc <counters> --kernel-trace -d gpurun_out/x -o r -- python3 scripts/spmm_pmc_workload.py [C]"""
 import os
@@ -13,7 +13,7 @@ from dual_dmp_amd.mesh import Mesh           # noqa: E402
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device("cuda:0")
 v, f = synth.torus(1000, 500)
-v, f = synth.morton_relabel(v, f)
+v, f = synth.rcb_relabel(v, f)               # (the engines' numbering since round 5; Morton before)
 m = Mesh(vs=v, faces=f)
 e = torch.tensor(m.edges.T, dtype=torch.long)
 ei = torch.cat([e, e[[1, 0]]], 1).to(dev)
