@@ -20,6 +20,10 @@ Rank 0 prints ONE JSON line (schema in the task contract) with extra objects:
                       stream in a separate profiled pass of the same step; + "roofline_gather" for the GCN gather
   cpu_baseline        the oracle's PyG-shaped PyTorch-CPU training step timed on this host (bounded sample)
   gate_open_ms_per_step, random_order_ms_per_step, eval_block_ms     SURVEY.md §8d's side figures (untimed region)
+  irregular_ms_per_step + "irregular"   the same step on the same vertices after random edge flips + a valence-24 hub (irregular
+                      valence: rows of 4 ... 25 entries on the vertex graph), with its own roofline_gather
+  device_copy         the yardsticks measured on this box: the library's own streaming copy (ddmp_copy_probe, plain / nontemporal),
+                      the same bytes in the gather's access pattern (ddmp_copy_probe_rows), torch's copy_, the guide's 6.29 TB/s
 """
 import argparse
 import hashlib

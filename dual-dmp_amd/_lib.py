@@ -92,6 +92,11 @@ def lib():
         fn.argtypes = [t for t, _ in sig]
     if handle.ddmp_abi_version() != 3:
         raise DdmpError("libddmp_hip.so ABI version mismatch")
+    abl = handle.ddmp_build_ablation_flags()
+    if abl and not os.environ.get("DDMP_LIB"):
+        raise DdmpError("%s is a timing-only ablation build (flags %d: parts of its kernels are compiled out, results are WRONG); "
+                        "rebuild with `make -C dual-dmp_amd/csrc clean all`, or name a diagnostic build explicitly through DDMP_LIB"
+                        % (LIB_PATH, abl))
     _lib = handle
     return _lib
 

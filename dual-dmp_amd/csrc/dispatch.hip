@@ -126,6 +126,30 @@ extern "C" int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mo
     return DDMP_OK;
 }
 
+// The GEMM sources carry compile-time hooks for timing-only A/B builds (scripts/build_ablation*.sh, scripts/rr_ablation.sh:
+// -DDDMP_ABLATE / _PANEL_ABLATE / _RR_ABLATE / _TN_ABLATE remove parts of a kernel; RESULTS ARE WRONG in such builds).  A
+// library built with any of them says so here, and the Python host side refuses to load it as the product library
+// (dual-dmp_amd/_lib.py; tests/test_cli_cpu.py asserts 0 for the in-tree build).
+extern "C" int ddmp_build_ablation_flags(void) {
+    int f = 0;
+#ifdef DDMP_ABLATE
+    f |= 1;
+#endif
+#ifdef DDMP_PANEL_ABLATE
+    f |= 2;
+#endif
+#if defined(DDMP_RR_ABLATE) && DDMP_RR_ABLATE != 0
+    f |= 4;
+#endif
+#ifdef DDMP_TN_ABLATE
+    f |= 8;
+#endif
+#ifdef DDMP_NO_NT
+    f |= 16;
+#endif
+    return f;
+}
+
 // ---------------------------------------------------------------- tail-fused finalisation of column reductions (finalize.h)
 namespace ddmp {
 static thread_local FinalizeArgs g_fin_pending, g_fin_active;

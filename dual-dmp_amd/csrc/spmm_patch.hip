@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         s_perm[chunk_rank_desc(min((nn_l + 3) >> 2, 31), lane)] = lane;
     }
     const int e0 = s_rowptr[0];
-    const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (dispatcher: max_row_nnz <= 16)
+    const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (graph.hip: a chunk with more entries is heavy)
     for (int t = tid; t < ne; t += 256) {
         s_lc[t] = lcol[e0 + t];
         s_w[t] = dinv[col[e0 + t]];
@@ -260,11 +260,16 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
 #pragma unroll
                 for (int k0 = 0; k0 < NEc; k0 += 4) {
                     if (k0 >= nmax) break;                       // (uniform)
+                    // the quad's fourth entry is padding for EVERY row of the wave when nmax == k0 + 3 (the 7-entry vertex graph of
+                    // a regular mesh, as in the lean kernel): its LDS read and its four FMAs with weight 0 are skipped wave-wide
+                    const bool fourth = k0 + 3 < nmax;           // (uniform)
                     uint4 v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + k]);
+                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + k]);
+                    if (fourth) v[3] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + 3]);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        if (k == 3 && !fourth) break;
                         float t[VW];
                         Lane<T>::unpack(v[k], t);
 #pragma unroll
@@ -446,9 +451,9 @@ int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, in
 //                                     with the fused reduction 1342 vs 1271 / 664 vs 646; C = 128 227 vs 209
 //   vertex graph (7 entries per row)  plain C = 512 468 vs 558, C = 256 251 vs 272; prologue C = 256 264 vs 289, C = 512 581 vs 597;
 //                                     with the fused reduction 897 vs 755 / 367 vs 384; C = 128 152 vs 132
-// (before the entries moved to registers the vertex graph lost everywhere: 583 / 277 us plain).  DDMP_SPMM_PATCH: unset = the
-// selection that follows from this (float32, rows of <= 8 entries, plain C >= 256 | prologue 256 <= C < 512), 0 = never,
-// 1 = wherever it applies (A/B runs).
+// (before the entries moved to registers the vertex graph lost everywhere: 583 / 277 us plain).  Round 5 (RCB numbering, patch_forms
+// below): every form from C = 256 wins or ties.  DDMP_SPMM_PATCH: unset = the measured selection (ddmp_spmm_patch_selected), 0 =
+// never, 1 = wherever it applies (A/B runs).
 int patch_max_nnz() {                                             // DDMP_SPMM_PATCH_MAXNNZ=5: the face graph only (A/B)
     static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_MAXNNZ"); return (e && atoi(e) > 0) ? atoi(e) : (1 << 30); }();
     return v;

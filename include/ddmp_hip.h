@@ -85,8 +85,10 @@ int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t
 int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
                   const float* bias, const float* pro_scale, const float* pro_shift, float slope,
                   ddmp_stream stream);
-/* 1: ddmp_spmm* runs its LDS-patch form for this graph and shape (float32 features, <= 8 entries per row, C >= 256, from 64k
- * rows: distinct rows of a 64-row chunk copied to LDS once, gathers from LDS -- csrc/spmm_patch.hip); same results either way */
+/* 1: ddmp_spmm* runs its LDS-patch form for this graph and shape (graphs from 64k rows with <= 12 entries per row on average,
+ * C >= 256; rows of any length -- the selection is per 64-row chunk since round 5, chunks the form cannot take go to the lean
+ * gather; has_red: 0 | 1 the fused BatchNorm-backward reduction | 2 the fused statistics; dtype DDMP_BF16: plain, prologue and
+ * statistics only): distinct rows of a chunk copied to LDS once, gathers from LDS -- csrc/spmm_patch.hip; same results either way */
 int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red);
 
 /* ------------------------------------------------------------------ dense steps (MFMA; float32 operands and results, the
@@ -496,6 +498,10 @@ int ddmp_comm_allgather(ddmp_comm* comm, const void* send, void* recv, int64_t b
 /* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
 /* a one-thread kernel named ddmp_trace_marker_kernel: brackets a region in a rocprofv3 kernel trace (measurement aid) */
 int ddmp_trace_marker(ddmp_stream stream);
+/* 0 for the product library; a bit mask of the timing-only ablation macros a diagnostic build was compiled with (such builds
+ * compute WRONG results: scripts/build_ablation*.sh).  The Python host side refuses a non-zero library unless it was named
+ * explicitly through DDMP_LIB. */
+int ddmp_build_ablation_flags(void);
 /* measurement aid (bench.py's copy yardstick): a streaming device copy of `bytes` (multiple of 16, both pointers 16-byte
  * aligned) written like the library's HBM-bound kernels; mode 0 plain, 1 nontemporal loads / stores */
 int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_stream stream);

@@ -15,6 +15,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(lib, name), name
     assert lib.ddmp_abi_version() == 3
+    assert lib.ddmp_build_ablation_flags() == 0            # the in-tree library is never a timing-only ablation build
     assert _lib.status_string(0) == "ok" and _lib.status_string(-4) == "workspace too small"
     # argument validation happens before any device work
     assert lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None) == -1

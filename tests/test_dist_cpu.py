@@ -16,7 +16,11 @@ sys.path.insert(0, HERE)
 def _mesh(kind="ico2"):
     from dual_dmp_amd import synth
     from dual_dmp_amd.datamaker import dataset_from_meshes
-    v, f = synth.icosphere(2) if kind == "ico2" else synth.open_grid(9, 7)
+    if kind == "flip":                                           # irregular valence (round 5): flipped torus + a valence-16 hub
+        v, f = synth.torus(14, 8)
+        f = synth.add_hub(v, synth.flip_edges(v, f, rounds=8, seed=3), 5, 16)
+    else:
+        v, f = synth.icosphere(2) if kind == "ico2" else synth.open_grid(9, 7)
     v, f = synth.permute_vertices(v, f, 2)
     gt, noisy, smooth = synth.make_triplet(v, f)
     return noisy, smooth, dataset_from_meshes(noisy, smooth)
@@ -117,12 +121,13 @@ def _compare(ref, got, ref_nets, tag):
         assert float((n0 - n1).abs().max()) < 2e-5, (tag, s)
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P):
+@pytest.mark.parametrize("P,kind", [(2, "ico2"), (3, "ico2"), (3, "flip")])
+def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P, kind):
+    """(kind "flip": an irregular-valence mesh -- rows of 4 ... 17 entries, the hub's 1-ring spread over the ranks)"""
     import cpu_ops_stub as stub
     from dual_dmp_amd import dist as D
     _patch(monkeypatch.setattr, stub)
-    noisy, smooth, data = _mesh("ico2")
+    noisy, smooth, data = _mesh(kind)
     ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
     comms = D.ThreadComm.make(P)
     results = {}
