@@ -367,8 +367,15 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
     const int n = (int)g->n_rows;
     if (chunk_list) {
         if (n_list <= 0) return DDMP_OK;
-        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
-                           Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
+        // a handful of chunks (the regular 1M-face mesh in RCB order leaves ~100 of 15,625 face chunks to this launch): one
+        // workgroup per chunk would walk its C / 32 slabs in sequence on ~100 CUs while the rest of the chip idles -- the slabs of a
+        // chunk are split over workgroups (the kernel's slab groups), ~2048 workgroups in all
+        const int n_sl = std::max(C / 32, 1);
+        const int want = std::min(n_sl, std::max(1, 2048 / n_list));
+        const int per = (n_sl + want - 1) / want;
+        const int groups_l = (n_sl + per - 1) / per;
+        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list, groups_l), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X,
+                           ldx, Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
         LAUNCH_TRY();
         return DDMP_OK;
     }

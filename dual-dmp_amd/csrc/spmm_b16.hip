@@ -164,9 +164,13 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
 
     const int lane = tid & 63, wave = tid >> 6;
     const int grp = lane / LANES, sl = lane % LANES;
+    // slab groups (gridDim.y > 1: the heavy-chunk launches): this workgroup walks only its share of the C / CS slabs
+    const int n_slabs_all = (C + CS - 1) / CS;
+    const int slabs_per_group = (n_slabs_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c_begin = (int)blockIdx.y * slabs_per_group * CS, c_end = min(C, c_begin + slabs_per_group * CS);
     auto slabs = [&](auto slots_tag) {
     constexpr bool SLOTS = decltype(slots_tag)::value;           // LEAN and the chunk's slots fit: entries from s_ent
-    for (int c0 = 0; c0 < C; c0 += CS) {
+    for (int c0 = c_begin; c0 < c_end; c0 += CS) {
         const int off = c0 + sl * VW;
         float pa[VW], pb[VW], k1[VW], k0[VW];
         float q0[VW], q1[VW];
@@ -352,7 +356,11 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
     const int n_chunks = heavy ? n_heavy : (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     if (heavy && n_heavy <= 0) return DDMP_OK;
-    const dim3 grid(heavy ? n_heavy : cpx * kXcd);
+    // (a chunk list: the slabs of a chunk are split over workgroups, ~2048 in all -- see launch_lean in spmm.hip)
+    const int n_sl = std::max((C + LANES * VW - 1) / (LANES * VW), 1);
+    const int want = heavy ? std::min(n_sl, std::max(1, 2048 / n_heavy)) : 1;
+    const int per = (n_sl + want - 1) / want;
+    const dim3 grid(heavy ? n_heavy : cpx * kXcd, heavy ? (n_sl + per - 1) / per : 1);
     // lean staging where the rows fit their slots and the offsets (16-byte units) fit 32 bits; DDMP_SPMM_LEAN=0 for A/B
     static int lean_on = -1;
     if (lean_on < 0) {
