@@ -131,21 +131,27 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
         const int ln = tid & 63;
         const int nn_l = ln < nr ? s_rowptr[ln + 1] - s_rowptr[ln] : 0;
         const int nq_l = (nn_l + 3) >> 2;
-        int incl = nq_l;
+        const int nq0 = __builtin_amdgcn_readfirstlane(nq_l);   // (regular meshes: one ballot instead of the scan, spmm_lean.inc)
+        const bool uni = __ballot(nq_l != nq0) == 0ull;
+        int incl = (ln + 1) * nq0;
+        if (!uni) {
+            incl = nq_l;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (ln >= o) incl += t;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (ln >= o) incl += t;
+            }
         }
         const int qoff_l = incl - nq_l;
-        staged = __shfl(incl, 63, 64) * 4 <= kMaxE;              // (the same in every wave)
+        staged = (uni ? 64 * nq0 : __shfl(incl, 63, 64)) * 4 <= kMaxE;   // (the same in every wave)
         const int rank_l = chunk_rank_desc(ln < nr ? min(nq_l, 31) : -1, ln);
         if (tid < 64) s_perm[rank_l] = ln;
         if (tid < nr) s_slot[tid] = staged ? qoff_l * 512 + nq_l : 0;
         if (staged) {
             const int lr = tid >> 2;
-            const int qo = __shfl(qoff_l, lr, 64), nq = __shfl(nq_l, lr, 64), nn = __shfl(nn_l, lr, 64);
             const int rb = s_rowptr[min(lr, nr)];
+            const int nn = lr < nr ? s_rowptr[lr + 1] - rb : 0, nq = (nn + 3) >> 2;
+            const int qo = uni ? lr * nq0 : __shfl(qoff_l, lr, 64);
             for (int k = tid & 3; k < 4 * nq; k += 4) {          // padding: the row's last entry again, weight 0
                 const int c = col[rb + min(k, nn - 1)];
                 s_ent[4 * qo + k] = make_uint2((unsigned)c * ld16, k < nn ? __float_as_uint(dinv[c]) : 0u);
