@@ -94,6 +94,44 @@ __device__ __forceinline__ int chunk_rank_desc(int key, int lane) {
     return rank;
 }
 
+// Two-term _Float16 split of (already scaled) floats for the f16x3 GEMMs: h = f16(v) packed by v_cvt_pk_f16_f32, m = f16(v - h) by
+// ONE v_fma_mix per element -- the instruction reads the f16 half of h in place, subtracts in f32 (the difference of a float and
+// its own f16 rounding is exact) and rounds once: the same bits as (_Float16)(v - (float)h), without the conversion of h back to
+// f32 and without the separate packing of m.  Left to itself hipcc builds half of the elements that way and the other half as
+// cvt_f32_f16 + pk_fma + cvt_pk: 3.7 VALU operations per element in the wide wgrad's loop instead of 2.5, in kernels that are
+// short of issue slots.  Four elements per asm statement, the two halves of a register written by instructions that
+// are NOT adjacent: a partial (op_sel) write followed at once by a read of the same register costs a wait state (hipcc pads
+// such pairs with s_nop when it sees them; inside one statement nobody does, so the order below keeps them apart and the
+// statement ends with the wait state its last write may owe the next reader).
+__device__ __forceinline__ void f16_split_quad(float4 v, uint2& h, uint2& m) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    h2_t a, b;
+    a[0] = (_Float16)v.x; a[1] = (_Float16)v.y;
+    b[0] = (_Float16)v.z; b[1] = (_Float16)v.w;
+    h.x = __builtin_bit_cast(unsigned, a);
+    h.y = __builtin_bit_cast(unsigned, b);
+    asm("v_fma_mixlo_f16 %0, %2, 1.0, -%6 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %4, 1.0, -%7 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, 1.0, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, 1.0, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(m.x), "=&v"(m.y) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(h.x), "v"(h.y));
+}
+// The same split of x * s for a power-of-two scale s (the products are exact): the scale rides in the instructions' second
+// source and no scaled copy of the operand is ever formed -- two v_fma_mix per element.
+__device__ __forceinline__ void f16_split_quad_scaled(float4 x, float s, uint2& h, uint2& m) {
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(h.x), "=&v"(h.y), "=&v"(m.x), "=&v"(m.y) : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(s));
+}
+
 // Sum over the 8 lanes l, l ^ 8, l ^ 16, l ^ 32 ... that share (lane & 7) -- the 8 row groups of a wave in the gather kernels'
 // fused-reduction epilogues.  __shfl_xor compiles to ds_bpermute_b32 (the LDS crossbar: 24 of them per wave and 128-byte slab
 // were a third of the statistics epilogue's cost on the 7-entry vertex graph); here one DPP add within the 16-lane row and the

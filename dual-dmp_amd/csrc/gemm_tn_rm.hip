@@ -200,14 +200,20 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
     // the wave that saw it raises the slot's flag (f16s_publish) and the heal launch, which follows every stale-scale launch,
     // redoes the whole product with the exact scale and overwrites these partials (gemm_f16s.inc).
     auto split_store = [&](float4 v, _Float16* p0, _Float16* p1) __attribute__((always_inline)) {
-        f16x4 h, m;
-        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-        m[0] = (_Float16)(v.x - (float)h[0]); m[1] = (_Float16)(v.y - (float)h[1]);
-        m[2] = (_Float16)(v.z - (float)h[2]); m[3] = (_Float16)(v.w - (float)h[3]);
-        *reinterpret_cast<f16x4*>(p0) = h;
-        *reinterpret_cast<f16x4*>(p1) = m;
+        uint2 h, m;                                              // (f16_split_quad: cvt_pk + one v_fma_mix per element)
+        f16_split_quad(v, h, m);
+        *reinterpret_cast<uint2*>(p0) = h;
+        *reinterpret_cast<uint2*>(p1) = m;
     };
-    // (maxima of the SCALED operands; f16s_publish gets them un-scaled -- exactly, the scales are powers of two)
+    // a plain operand: the scale rides in the conversion instructions (f16_split_quad_scaled), the maximum is taken raw
+    auto split_store_scaled = [&](float4 x, float s, _Float16* p0, _Float16* p1) __attribute__((always_inline)) {
+        uint2 h, m;
+        f16_split_quad_scaled(x, s, h, m);
+        *reinterpret_cast<uint2*>(p0) = h;
+        *reinterpret_cast<uint2*>(p1) = m;
+    };
+    // (maxima of the operands as they are converted: SCALED where a prologue carries the scale -- f16s_publish gets those un-scaled,
+    //  exactly, the scales are powers of two -- raw for a plain operand)
     auto amax4 = [](float m, float4 v) { return fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fmaxf(fabsf(v.z), fabsf(v.w)))); };
     auto store_g = [&](int buf, const Slot& sl, int stage) __attribute__((always_inline)) {
         int co = gc4;
@@ -227,8 +233,6 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
                 x.y = fmaf(ca.y, x.y * (fmaf(y.y, ca.y, cb.y) > 0.f ? sg : sgs), fmaf(k1.y, y.y, k0.y));
                 x.z = fmaf(ca.z, x.z * (fmaf(y.z, ca.z, cb.z) > 0.f ? sg : sgs), fmaf(k1.z, y.z, k0.z));
                 x.w = fmaf(ca.w, x.w * (fmaf(y.w, ca.w, cb.w) > 0.f ? sg : sgs), fmaf(k1.w, y.w, k0.w));
-            } else {
-                x.x *= sg; x.y *= sg; x.z *= sg; x.w *= sg;
             }
             if (MASK) {
                 const int row = r_begin + stage * kRows + grow_s(p) + grow_l;      // (scalar for a 256-wide operand)
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
             }
             gmax = amax4(gmax, x);
             const int o = rm_off<TM>(grow_s(p) + grow_l, gc4);
-            split_store(x, &Gs[buf][0][o], &Gs[buf][1][o]);
+            if (GDUAL) split_store(x, &Gs[buf][0][o], &Gs[buf][1][o]);
+            else split_store_scaled(x, sg, &Gs[buf][0][o], &Gs[buf][1][o]);
         }
     };
     // (PRO: rows past the split read as 0 through the descriptor and the prologue maps them to lrelu(shift) != 0 -- harmless for
@@ -256,12 +261,11 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
                 const float4 sc = *reinterpret_cast<const float4*>(&s_co[kCoZ][co]);
                 const float4 sh = *reinterpret_cast<const float4*>(&s_co[kCoZ + (PRO ? 1 : 0)][co]);
                 x = f4_affine_lrelu(x, sc, sh, slope);
-            } else {
-                x.x *= sz; x.y *= sz; x.z *= sz; x.w *= sz;
             }
             zmax = amax4(zmax, x);
             const int o = rm_off<TK>(zrow_s(p) + zrow_l, zc4);
-            split_store(x, &Zs[buf][0][o], &Zs[buf][1][o]);
+            if (PRO) split_store(x, &Zs[buf][0][o], &Zs[buf][1][o]);
+            else split_store_scaled(x, sz, &Zs[buf][0][o], &Zs[buf][1][o]);
         }
     };
 
@@ -433,8 +437,8 @@ __global__ __launch_bounds__(512) void gemm_tn_rm_kernel(const TnRmArgs a) {
             }
     }
     if (!a.heal) {
-        f16s_publish(a.gslot, gmax * (1.f / sg), sg);
-        f16s_publish(a.zslot, zmax * (1.f / sz), sz);
+        f16s_publish(a.gslot, GDUAL ? gmax * (1.f / sg) : gmax, sg);
+        f16s_publish(a.zslot, PRO ? zmax * (1.f / sz) : zmax, sz);
     }
 }
 
