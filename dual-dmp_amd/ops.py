@@ -612,7 +612,9 @@ def gemm_nn(a, w, out=None, n_rows=None, wplanes=None, scales=None):
 
 
 def gemm_nn_bnred_supported(M, K, n_rows, dtype=torch.float32):
-    """Does gemm_nn_bnred exist for a dgrad M -> K over n_rows rows (float32 features, row-register kernel)?"""
+    """Does gemm_nn_bnred exist for a dgrad M -> K over n_rows rows (row-register kernels; bfloat16 features: round 5)?"""
+    if dtype == torch.bfloat16:
+        return bool(_lib.lib().ddmp_gemm_nn_bnred_bf16_supported(int(M), int(K), int(n_rows)))
     return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_nn_bnred_supported(int(M), int(K), int(n_rows)))
 
 
@@ -622,13 +624,24 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
     from the GEMM epilogue -- one read of yp instead of a pass over out and yp."""
     a, lda = _mat(a, "a")
     w, ldw = _mat(_chk(w, torch.float32, "w"), "w")
-    yp, ldyp = _mat(yp, "yp")
+    yp, ldyp = _mat(yp, "yp", a)
     n = a.shape[0] if n_rows is None else n_rows
     M, K = w.shape
     if out is None:
-        out = torch.empty((n, K), dtype=torch.float32, device=a.device)
-    out, ldo = _mat(out, "out")
+        out = torch.empty((n, K), dtype=a.dtype, device=a.device)
+    out, ldo = _mat(out, "out", a)
     L = _lib.lib()
+    if a.dtype == torch.bfloat16:
+        nb = (L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)) + 255) // 256 * 256
+        sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, K)
+        ws = Workspace.get(nb + sb, a.device)
+        with _timed("gemm_nn", (M, K), 2.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
+            o, keep = _mk_opts(bn, want_bn=True)
+            st = L.ddmp_gemm_nn_bnred_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
+                                             _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(ws), nb, ws.data_ptr() + nb,
+                                             ws.numel() - nb, _stream(), o)
+        check(st, "ddmp_gemm_nn_bnred_bf16")
+        return out
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
     ws = Workspace.get(nb + sb, a.device)

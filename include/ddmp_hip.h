@@ -161,7 +161,7 @@ int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const fl
                             const float* rstd, float* dgamma, float* dbeta, float* c1, float* c0,
                             ddmp_stream stream);
 /* Tail-fused coefficients (round 3): arm the NEXT call on this host thread that produces a float64 [2C] column reduction
- * (ddmp_bn_stats*, ddmp_gemm_nt_stats_*, ddmp_bn_bwd_reduce*, ddmp_spmm_bnred*, ddmp_gemm_nn_bnred_f32) so that the second
+ * (ddmp_bn_stats*, ddmp_gemm_nt_stats_*, ddmp_bn_bwd_reduce*, ddmp_spmm_bnred*, ddmp_gemm_nn_bnred_f32 / _bf16) so that the second
  * stage of that reduction ALSO writes what ddmp_bn_prepare_f32 / ddmp_bn_bwd_prepare_f32 would (same arithmetic, bitwise the
  * same values; the sums are still written) -- one launch less per BatchNorm and direction.  C must be the reduction's width.
  * No device work, no stream: the arguments are remembered until that call; ddmp_bn_next_cancel drops them. */
@@ -433,7 +433,20 @@ int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t
  *   ddmp_gemm_nn_bnbwd_bf16         out[n,K] = dY . W[M,K], dY = bf16(a dZ lrelu'(a Yb + b) + c1 Yb + c0) rebuilt on the operand
  *                                   load: what ddmp_bn_bwd_apply_bf16 would have written, never stored
  *   ddmp_gemm_tn_bnbwd_bf16         dW[M,K] = dY^T . f(Z), the same dY (reference op: GCNConv.lin backward behind
- *                                   BatchNorm1d + LeakyReLU, util/networks.py:31-44,51-62) */
+ *                                   BatchNorm1d + LeakyReLU, util/networks.py:31-44,51-62)
+ *   ddmp_gemm_nn_bnred_bf16         (round 5; the bf16 twin of ddmp_gemm_nn_bnred_f32) out[n,K] = bf16(A[n,M] . W[M,K]) AND
+ *                                   sums2[2K] = ddmp_bn_bwd_reduce_bf16(out, Yp, ...) of the output AS STORED, from the epilogue
+ *                                   (one read of Yp instead of a pass over out and Yp); workspace >=
+ *                                   ddmp_gemm_rows_bf16_workspace_bytes(M, K), stats_ws >= ddmp_gemm_nt_stats_bf16_workspace_bytes
+ *                                   (n_rows, K); DDMP_EINVAL for shapes the row-register kernel does not take.  ..._supported:
+ *                                   the shapes an engine should route here -- none by default, the form measured no gain inside
+ *                                   the step (csrc/gemm_b16.hip); DDMP_BF16_GEMM_BNRED=1 for A/B */
+int ddmp_gemm_nn_bnred_bf16_supported(int M, int K, int64_t n_rows);
+int ddmp_gemm_nn_bnred_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out,
+                            int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
+                            void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
+                            ddmp_stream stream);
 int ddmp_gemm_fused_bf16_supported(int cout, int cin, int64_t n_rows);
 size_t ddmp_gemm_nt_stats_bf16_workspace_bytes(int64_t n_rows, int M);
 int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
@@ -608,6 +621,10 @@ int ddmp_gemm_nt_stats_bf16_o(const uint16_t* A, int64_t lda, const float* W, in
     const ddmp_opts* opts);
 int ddmp_gemm_nn_bnred_f32_o(const float* A, int64_t lda, const float* W, int64_t ldw, float* out, int64_t ld_out,
     int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale, const float* shift,
+    const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
+    void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts);
+int ddmp_gemm_nn_bnred_bf16_o(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out,
+    int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift,
     const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
     void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts);
 int ddmp_gemm_nn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,

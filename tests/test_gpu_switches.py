@@ -41,6 +41,7 @@ BF16_SWITCHES = [
     {"DDMP_SPMM_PATCH_FORMS": "7"},            # bf16 features stay off the LDS-patch gather (round-4 selection)
     {"DDMP_BF16_SPMM_BNRED": "0"},             # backward reductions as separate passes
     {"DDMP_BF16_FUSE": "0"},                   # no BatchNorm backward on the GEMM operand loads
+    {"DDMP_BF16_GEMM_BNRED": "1"},             # transform-first dgrads with the reductions epilogue (round 5; off by default)
     {"DDMP_TN_DMA": "0"},
     {"DDMP_SPMM_B16_VW": "4"},
     {"DDMP_GEMM_RR": "0"},
