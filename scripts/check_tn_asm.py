@@ -5,7 +5,9 @@ MFMAs).  For every instantiation this checks the main loops (the basic blocks th
   (1) ONE basic block per loop: 48 MFMAs (24 in the 256 x 128 / 128 x 256 panels), the stage's buffer loads, fragment reads and LDS writes of two iterations in it --
       no load sits in a side block;
   (2) no scratch (spill) traffic in it;
-  (3) no `s_waitcnt vmcnt(0)`: every wait leaves the younger stage's loads in flight.
+  (3) no `s_waitcnt vmcnt(0)`: every wait leaves the younger stage's loads in flight;
+  (4) (round 5) the f16 split is the v_fma_mix form of ddmp_common.h: no f16 -> f32 conversion (v_cvt_f32_f16) in the loop -- what
+      hipcc emitted for half of the elements when the split was written as casts (3.7 instead of 2.5 VALU per element).
     usage: check_tn_asm.py [gemm_tn_rm_dev.s]     (compiles csrc/gemm_tn_rm.hip --cuda-device-only -S if omitted)"""
 import os, re, subprocess, sys, tempfile
 
@@ -61,6 +63,10 @@ for st in starts:
             bad.append("%d scratch operations" % n_scratch)
         if any(w == 0 for w in waits):
             bad.append("vmcnt(0) in the loop: waits %s" % waits)
+        n_back = sum(t.startswith("v_cvt_f32_f16") for t in ins)
+        n_mix = sum(t.startswith("v_fma_mix") for t in ins)
+        if n_back or not n_mix:
+            bad.append("%d v_cvt_f32_f16, %d v_fma_mix: the split is not the v_fma_mix form" % (n_back, n_mix))
         print("%s %s: %d instructions, %d MFMA, %d loads, vmcnt waits %s%s" % (
             tag, name, len(ins), n_mfma, n_ld, waits, ("   <-- " + "; ".join(bad)) if bad else ""))
         problems += bool(bad)
