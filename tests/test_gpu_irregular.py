@@ -231,6 +231,44 @@ def test_csr_host_graph_with_empty_rows_at_patch_size(dev):
     assert torch.equal(y[empty], bias.expand(len(empty), -1))     # an empty row aggregates nothing: bias exactly
 
 
+def _random_csr(seed, n, nc, band):
+    """Random CSR: heavy-tailed row lengths (many 0 ... 12, a few 30 ... 90, now and then several hundred), columns anywhere
+    (band = 0) or within +-band of the row (a graph with locality: what the LDS-patch tables are built for); repeated columns
+    allowed."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 13, size=n)
+    k = max(1, n // 50)
+    lens[rng.integers(0, n, size=k)] = rng.integers(30, 90, size=k)
+    lens[rng.integers(0, n, size=3)] = rng.integers(200, 700, size=3)
+    if seed % 2:
+        lens[: min(n, 70)] = 0                                    # an empty first chunk
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(n), lens)
+    if band:
+        col = (rows * (nc / n)).astype(np.int64) + rng.integers(-band, band + 1, size=len(rows))
+        col = np.clip(col, 0, nc - 1).astype(np.int32)
+    else:
+        col = rng.integers(0, nc, size=len(rows)).astype(np.int32)
+    dinv = (rng.random(max(n, nc)) * 0.9 + 0.1).astype(np.float32)
+    return rowptr, col, dinv
+
+
+@pytest.mark.parametrize("seed,n,nc,band,C", [
+    (1, 63, 63, 0, 32), (2, 64, 90, 0, 64), (3, 65, 65, 0, 256), (4, 129, 129, 0, 128), (5, 4097, 4097, 0, 512),
+    (6, 1000, 5000, 0, 64), (7, 70001, 70001, 40, 256), (8, 66000, 66000, 25, 512), (9, 70001, 70001, 0, 256),
+    (10, 131072, 131072, 60, 256), (11, 5000, 5000, 30, 16), (12, 65536, 70000, 50, 128)])
+def test_gather_forms_on_random_csr_graphs(dev, seed, n, nc, band, C):
+    """Fuzz: every form of the gather on random CSR graphs -- sizes around the 64-row chunk and the 64k-row threshold of the
+    LDS-patch tables, rows of 0 ... several hundred entries, with and without locality, square and rectangular -- against the
+    float64 sparse product, float32 and bfloat16."""
+    rowptr, col, dinv = _random_csr(seed, n, nc, band)
+    gr = G(dev, rowptr, col, dinv[:nc], nc)
+    for dtype, tol in ((torch.float32, 3e-6), (torch.bfloat16, 4e-3)):
+        if dtype == torch.bfloat16 and C % 8:
+            continue
+        _forms(dev, gr, C, dtype, tol)
+
+
 SWITCHES = [{"DDMP_SPMM_PATCH": "1"}, {"DDMP_SPMM_PATCH": "0"}, {"DDMP_SPMM_PATCH_NE": "0"}, {"DDMP_SPMM_LEAN": "0"},
             {"DDMP_SPMM_PATCH": "1", "DDMP_SPMM_PATCH_NE": "0"}]
 
