@@ -15,6 +15,8 @@ ap.add_argument("--order", default="native")
 ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
 ap.add_argument("--flip", type=int, default=0, help="rounds of random edge flips (irregular valence)")
 ap.add_argument("--widths", default="512,256,128,64,32")
+ap.add_argument("--rotate", type=int, default=1, help="spmm: cycle through this many (input, output) buffer sets so that narrow "
+                "widths are not served from the 256 MB MALL (a 1M x 32 float tensor is 128 MB)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 n = a.rows
@@ -65,6 +67,33 @@ if a.what in ("spmm", "all"):
     for gname, idx, nn_ in (("face", fi, len(f)), ("vert", ei, len(v))):
         g = ops.graph_for(idx, nn_)
         for C in [int(c) for c in a.widths.split(",")]:
+            if a.rotate > 1:                                     # cold-cache figures: every launch works on another buffer set
+                R = a.rotate
+                Xs = [torch.randn(nn_, C, device=dev).to(DT) for _ in range(R)]
+                Ys = [torch.empty(nn_, C, device=dev, dtype=DT) for _ in range(R)]
+                Yps = [torch.randn(nn_, C, device=dev).to(DT) for _ in range(R)]
+                sc = torch.rand(C, device=dev) + 0.5; sh = torch.randn(C, device=dev)
+                bn4 = torch.rand(4, C, device=dev) + 0.5; c10 = torch.rand(2, C, device=dev) * 0.1
+                sums = torch.empty(2 * C, dtype=torch.float64, device=dev); ref0 = torch.zeros(C, device=dev)
+                k = [0]
+
+                def rot(fn):
+                    def go():
+                        i = k[0] % R; k[0] += 1
+                        fn(Xs[i], Ys[i], Yps[i])
+                    return go
+                it = max(a.iters, 2 * R)
+                t = {name: timeit(rot(fn), it) for name, fn in (
+                    ("plain", lambda X, Y, Yp: ops.spmm(g, X, out=Y)),
+                    ("prologue", lambda X, Y, Yp: ops.spmm(g, X, out=Y, pro=(sc, sh))),
+                    ("statistics", lambda X, Y, Yp: ops.spmm_stats(g, X, Y, ref0, sums, bias=sh)),
+                    ("reduction", lambda X, Y, Yp: ops.spmm_bnred(g, X, Y, Yp, bn4, sums)),
+                    ("bn-backward", lambda X, Y, Yp: ops.spmm_bnbwd(g, X, Yp, bn4, c10, Y)))}
+                b2, b3 = 2.0 * nn_ * C * ES, 3.0 * nn_ * C * ES
+                print("spmm %s N=%d C=%3d  cold (%d buffer sets): " % (gname, nn_, C, R) + "   ".join(
+                    "%s %5.0f us (%.2f TB/s)" % (nm, us, (b3 if nm in ("reduction", "bn-backward") else b2) / us / 1e6) for nm, us in t.items()), flush=True)
+                del Xs, Ys, Yps
+                continue
             X = torch.randn(nn_, C, device=dev).to(DT); Y = torch.empty(nn_, C, device=dev, dtype=DT)
             us = timeit(lambda: ops.spmm(g, X, out=Y))
             alg = 2.0 * nn_ * C * ES + 4.0 * g.nnz + 8.0 * nn_
