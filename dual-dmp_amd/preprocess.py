@@ -16,8 +16,10 @@ pymeshlab for three steps; here they are numpy, with these definitions --
   noisemaker.py:28-30): divide by the longest bounding-box side, move the bounding-box centre to the origin.  The
   edge-based rescale that follows makes the scale factor immaterial; only the centring survives.
 * ``laplacian_smooth(stepsmoothnum=step, cotangentweight=False)`` (noisemaker.py:25-26): MeshLab's source is not in the
-  reference tree; :func:`synth.laplacian_smooth` (p <- (p + 2 sum_nbr p_j) / (2 deg + 1)) is this build's own
-  definition -- parity with MeshLab is unpinned and said so in DESIGN.md.
+  reference tree and pymeshlab (==2021.10, requirements.txt:6) cannot be installed here; :func:`synth.laplacian_smooth` restates
+  the published algorithm of that filter -- vcglib's ``Smooth::VertexCoordLaplacian``: interior vertices
+  p <- (p + 2 sum_nbr p_j) / (2 deg + 1), border vertices averaged with their border neighbours only,
+  p <- (2 p + p_a + p_b) / 4 -- in float64 (MeshLab: float32).  No MeshLab output exists to pin it against: said so in DESIGN.md.
 """
 from __future__ import annotations
 
@@ -52,7 +54,7 @@ def normalize(vs: np.ndarray) -> np.ndarray:
 
 
 def smooth_mesh(mesh: Mesh, step: int) -> Mesh:
-    return Mesh(vs=synth.laplacian_smooth(mesh.vs, mesh.vv_ptr, mesh.vv_idx, steps=step), faces=mesh.faces)
+    return Mesh(vs=synth.laplacian_smooth(mesh.vs, mesh.vv_ptr, mesh.vv_idx, steps=step, faces=mesh.faces), faces=mesh.faces)
 
 
 def from_clean_obj(path: str, level: float = 0.2, step: int = 30, move_original: bool = True):

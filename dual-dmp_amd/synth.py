@@ -187,15 +187,52 @@ def gaussian_noise(vs, vn, level=0.2, seed=314):
     return vs + vn * noise
 
 
-def laplacian_smooth(vs, vv_ptr, vv_idx, steps=30):
+def border_edges(faces):
+    """Edges with ONE incident face, as an [nb, 2] array (empty for a closed mesh)."""
+    f = np.asarray(faces, dtype=np.int64)
+    he = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = np.sort(he, axis=1)
+    uniq, cnt = np.unique(key, axis=0, return_counts=True)
+    return uniq[cnt == 1]
+
+
+def laplacian_smooth(vs, vv_ptr, vv_idx, steps=30, faces=None):
+    """``ms.apply_filter("laplacian_smooth", stepsmoothnum=steps, cotangentweight=False)`` of the reference
+    (preprocess/noisemaker.py:25-26, preprocess/preprocess.py:22-24; pymeshlab==2021.10, requirements.txt:6) without MeshLab.
+
+    MeshLab's source is not part of the reference tree and pymeshlab cannot be installed here: this restates the published
+    algorithm behind that filter -- MeshLab 2021.10 "Laplacian Smooth" (filter_unsharp, FP_LAPLACIAN; its other parameters at their
+    defaults: Boundary = true, selected = false) = ``vcg::tri::Smooth<CMeshO>::VertexCoordLaplacian`` with
+    ``AccumulateLaplacianInfo`` (vcglib, vcg/complex/algorithms/smooth.h), per step and simultaneously for all vertices:
+
+    * every NON-border edge is visited from both of its faces and adds the opposite end point with weight 1 each time, so an
+      interior vertex moves to  (p + 2 sum_j p_j) / (2 deg + 1);
+    * a vertex on the border is averaged with its border neighbours only ("1D boundary smoothing"): its accumulator is reset to
+      (sum = p, count = 1) and every border edge adds the other end point once --  (p + (p + sum_b p_b)) / ((1 + n_b) + 1)  =
+      (2 p + p_a + p_b) / 4  on a manifold border.
+
+    ``faces`` (optional): needed to find the border; without it every edge counts as interior (closed meshes).  MeshLab keeps
+    coordinates in float32, this runs in float64: agreement to float32 rounding is the best a MeshLab run could show -- no such run
+    exists here (parity of this row is unpinned; the algorithm is restated, not guessed)."""
+    n = len(vs)
     deg = np.diff(vv_ptr).astype(np.float64)[:, None]
-    rows = np.repeat(np.arange(len(vs)), np.diff(vv_ptr))
-    p = vs.copy()
+    rows = np.repeat(np.arange(n), np.diff(vv_ptr))
+    be = border_edges(faces) if faces is not None else np.zeros((0, 2), dtype=np.int64)
+    on_border = np.zeros(n, dtype=bool)
+    on_border[be.ravel()] = True
+    nb = np.bincount(be.ravel(), minlength=n).astype(np.float64)[:, None]
+    p = np.asarray(vs, dtype=np.float64).copy()
     for _ in range(steps):
         s = np.zeros_like(p)
         for c in range(3):
-            s[:, c] = np.bincount(rows, weights=p[vv_idx, c], minlength=len(p))
-        p = (p + 2.0 * s) / (2.0 * deg + 1.0)
+            s[:, c] = np.bincount(rows, weights=p[vv_idx, c], minlength=n)
+        new = (p + 2.0 * s) / (2.0 * deg + 1.0)
+        if len(be):
+            sb = np.zeros_like(p)
+            np.add.at(sb, be[:, 0], p[be[:, 1]])
+            np.add.at(sb, be[:, 1], p[be[:, 0]])
+            new[on_border] = ((2.0 * p + sb) / (nb + 2.0))[on_border]
+        p = new
     return p
 
 
@@ -206,7 +243,7 @@ def make_triplet(vs, faces, level=0.2, steps=30):
     gt = Mesh(vs=gt.vs / scale, faces=faces)
     nvs = gaussian_noise(gt.vs, gt.vn, level=level)
     noisy = Mesh(vs=nvs, faces=faces)
-    svs = laplacian_smooth(noisy.vs, noisy.vv_ptr, noisy.vv_idx, steps=steps)
+    svs = laplacian_smooth(noisy.vs, noisy.vv_ptr, noisy.vv_idx, steps=steps, faces=faces)
     smooth = Mesh(vs=svs, faces=faces)
     return gt, noisy, smooth
 

@@ -93,3 +93,38 @@ def test_generators_and_triplet():
     v, f = synth.cube_cad(4)
     m = Mesh(vs=v, faces=f)
     assert len(f) == 12 * 16 and len(v) - m.edges_count + len(f) == 2
+
+
+def test_laplacian_smooth_follows_the_published_vcglib_rule():
+    """synth.laplacian_smooth restates MeshLab 2021.10's "Laplacian Smooth" (preprocess/noisemaker.py:25-26: pymeshlab
+    ``laplacian_smooth``, cotangentweight=False; vcglib Smooth::VertexCoordLaplacian): interior vertex <- (p + 2 sum_nbr p_j) /
+    (2 deg + 1); border vertex <- (2 p + p_a + p_b) / 4 with its two BORDER neighbours only; all vertices at once.  Checked by hand
+    on a 3 x 3 grid of vertices (8 triangles, one interior vertex) -- no MeshLab output exists to compare with."""
+    xs, ys = np.meshgrid(np.arange(3.0), np.arange(3.0), indexing="ij")
+    rng = np.random.default_rng(0)
+    v = np.stack([xs.ravel(), ys.ravel(), rng.random(9)], 1)            # vertex i * 3 + j at (i, j, random height)
+    idx = lambda i, j: i * 3 + j
+    f = []
+    for i in range(2):
+        for j in range(2):
+            f.append([idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)])
+            f.append([idx(i, j), idx(i + 1, j + 1), idx(i, j + 1)])
+    f = np.array(f)
+    m = Mesh(vs=v, faces=f)
+    be = synth.border_edges(f)
+    assert len(be) == 8 and 4 not in be                                  # the outer square; the centre vertex is interior
+    out = synth.laplacian_smooth(m.vs, m.vv_ptr, m.vv_idx, steps=1, faces=f)
+    nbr4 = sorted(m.vv_idx[m.vv_ptr[4]:m.vv_ptr[5]].tolist())
+    assert nbr4 == [0, 1, 3, 5, 7, 8]                                    # the 1-ring of the centre in this triangulation
+    assert np.allclose(out[4], (v[4] + 2 * v[nbr4].sum(0)) / (2 * 6 + 1))
+    assert np.allclose(out[1], (2 * v[1] + v[0] + v[2]) / 4)             # an edge-midpoint border vertex: interior neighbour 4 ignored
+    assert np.allclose(out[0], (2 * v[0] + v[1] + v[3]) / 4)             # a corner
+    # simultaneous update: two steps == the one-step map applied twice
+    two = synth.laplacian_smooth(m.vs, m.vv_ptr, m.vv_idx, steps=2, faces=f)
+    assert np.allclose(two, synth.laplacian_smooth(out, m.vv_ptr, m.vv_idx, steps=1, faces=f))
+    # a closed mesh has no border: with and without faces alike
+    vi, fi = synth.icosphere(1)
+    mi = Mesh(vs=vi, faces=fi)
+    assert len(synth.border_edges(fi)) == 0
+    assert np.array_equal(synth.laplacian_smooth(mi.vs, mi.vv_ptr, mi.vv_idx, steps=3, faces=fi),
+                          synth.laplacian_smooth(mi.vs, mi.vv_ptr, mi.vv_idx, steps=3))
