@@ -71,9 +71,12 @@ def from_clean_obj(path: str, level: float = 0.2, step: int = 30, move_original:
     g_mesh = Mesh(vs=normalize(src.vs), faces=src.faces)                       # pre-scaling & transformation
     g_mesh = Mesh(vs=g_mesh.vs / synth.mean_edge_length(g_mesh.vs, g_mesh.edges), faces=src.faces)   # re-scaling
     g_mesh.save(g_file)
-    n_mesh = Mesh(vs=synth.gaussian_noise(g_mesh.vs, g_mesh.vn, level=level), faces=src.faces)
+    # the reference adds the noise to the mesh it reads BACK from the saved file (noisemaker.py:65: coordinates at the OBJ
+    # writer's precision), and MeshLab smooths what it loads from the noisy file (noisemaker.py:75-77)
+    base = Mesh(g_file)
+    n_mesh = Mesh(vs=synth.gaussian_noise(base.vs, base.vn, level=level), faces=base.faces)
     n_mesh.save(n_file)
-    s_mesh = smooth_mesh(n_mesh, step)
+    s_mesh = smooth_mesh(Mesh(n_file), step)
     s_mesh.save(s_file)
     return g_mesh, n_mesh, s_mesh, root_dir
 
