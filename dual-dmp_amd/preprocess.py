@@ -9,7 +9,10 @@
         = preprocess/preprocess.py:12-79: a directory that holds ``*_noise.obj`` (and optionally ``*_gt.obj``), e.g. a
           real scan -> writes ``<name>_smooth.obj`` and rescales all of them to unit mean edge length of the noisy mesh.
 
-Same flags, same file names, same order of operations, same seed (314).  What differs, by necessity: the reference calls
+Same flags, same file names, same order of operations, same seed (314).  The scripts' numpy halves -- everything between
+the MeshLab calls: :func:`rescale_and_noise` (noisemaker.py:60-73) and :func:`rescale_saved` (preprocess.py:56-78) -- are PINNED:
+they reproduce byte for byte the OBJ files the reference's own functions write (tests/golden/noise_*.npz,
+tests/test_mesh.py::test_preprocess_numpy_halves_match_reference_golden).  What differs, by necessity: the reference calls
 pymeshlab for three steps; here they are numpy, with these definitions --
 
 * normalize (``transform_scale_normalize`` unit box + ``transform_translate_center_set_origin`` on the bbox centre,
@@ -57,6 +60,38 @@ def smooth_mesh(mesh: Mesh, step: int) -> Mesh:
     return Mesh(vs=synth.laplacian_smooth(mesh.vs, mesh.vv_ptr, mesh.vv_idx, steps=step, faces=mesh.faces), faces=mesh.faces)
 
 
+def rescale_and_noise(g_file: str, n_file: str, level: float = 0.2):
+    """The numpy half of noisemaker.py (:60-73), which needs no MeshLab and is PINNED to the reference's own output
+    (tests/golden/noise_*.npz): read the pre-saved ground truth back, rescale it to unit mean edge length
+    (``edge_based_scaling`` :32-36) and save it; read THAT file back (coordinates at the OBJ writer's precision), displace
+    every vertex along its normal by N(0, level) drawn with seed 314 (``gausian_noise`` :38-42) and save.
+    Returns (gt, noisy)."""
+    g_mesh = Mesh(g_file)
+    g_mesh = Mesh(vs=g_mesh.vs / synth.mean_edge_length(g_mesh.vs, g_mesh.edges), faces=g_mesh.faces)    # re-scaling
+    g_mesh.save(g_file)
+    base = Mesh(g_file)
+    n_mesh = Mesh(vs=synth.gaussian_noise(base.vs, base.vn, level=level), faces=base.faces)
+    n_mesh.save(n_file)
+    return g_mesh, n_mesh
+
+
+def rescale_saved(n_file: str, s_file: str, g_file=None):
+    """The numpy half of preprocess.py (:56-78), pinned like :func:`rescale_and_noise`: read the normalised files back, divide
+    all of them by the mean edge length of the NOISY mesh, save.  Returns (gt or None, noisy, smooth)."""
+    n_mesh, s_mesh = Mesh(n_file), Mesh(s_file)
+    g_mesh = Mesh(g_file) if g_file is not None and os.path.exists(g_file) else None
+    ave_len = synth.mean_edge_length(n_mesh.vs, n_mesh.edges)
+    out = []
+    for m, f in ((g_mesh, g_file), (n_mesh, n_file), (s_mesh, s_file)):
+        if m is None:
+            out.append(None)
+            continue
+        mm = Mesh(vs=m.vs / ave_len, faces=m.faces)
+        mm.save(f)
+        out.append(mm)
+    return out[0], out[1], out[2]
+
+
 def from_clean_obj(path: str, level: float = 0.2, step: int = 30, move_original: bool = True):
     """noisemaker.py:44-80.  Returns (gt, noisy, smooth, directory)."""
     root_dir = os.path.dirname(os.path.abspath(path))
@@ -68,14 +103,8 @@ def from_clean_obj(path: str, level: float = 0.2, step: int = 30, move_original:
     if move_original:
         os.makedirs(os.path.join(root_dir, "original"), exist_ok=True)
         shutil.move(path, os.path.join(root_dir, "original", os.path.basename(path)))
-    g_mesh = Mesh(vs=normalize(src.vs), faces=src.faces)                       # pre-scaling & transformation
-    g_mesh = Mesh(vs=g_mesh.vs / synth.mean_edge_length(g_mesh.vs, g_mesh.edges), faces=src.faces)   # re-scaling
-    g_mesh.save(g_file)
-    # the reference adds the noise to the mesh it reads BACK from the saved file (noisemaker.py:65: coordinates at the OBJ
-    # writer's precision), and MeshLab smooths what it loads from the noisy file (noisemaker.py:75-77)
-    base = Mesh(g_file)
-    n_mesh = Mesh(vs=synth.gaussian_noise(base.vs, base.vn, level=level), faces=base.faces)
-    n_mesh.save(n_file)
+    Mesh(vs=normalize(src.vs), faces=src.faces).save(g_file)                   # pre-scaling & transformation, pre-saving
+    g_mesh, n_mesh = rescale_and_noise(g_file, n_file, level)
     s_mesh = smooth_mesh(Mesh(n_file), step)
     s_mesh.save(s_file)
     return g_mesh, n_mesh, s_mesh, root_dir
@@ -99,16 +128,11 @@ def from_noisy_dir(directory: str, step: int = 30):
     lo, hi = allv.min(0), allv.max(0)
     side = float((hi - lo).max()) or 1.0
     centre = 0.5 * (lo + hi)
-    nv = (n_mesh.vs - centre) / side
-    ave_len = synth.mean_edge_length(nv, n_mesh.edges)
-    out = []
-    for m, f in ((g_mesh, g_file), (n_mesh, n_file), (s_mesh, s_file)):
-        if m is None:
-            out.append(None)
-            continue
-        mm = Mesh(vs=(m.vs - centre) / side / ave_len, faces=m.faces)
-        mm.save(f)
-        out.append(mm)
+    # MeshLab saves the normalised layers (preprocess.py:29-40); the script then reads them back and rescales (:56-78)
+    for m, f in ((s_mesh, s_file), (g_mesh, g_file), (n_mesh, n_file)):
+        if m is not None:
+            Mesh(vs=(m.vs - centre) / side, faces=m.faces).save(f)
+    out = rescale_saved(n_file, s_file, g_file)
     return out[0], out[1], out[2], directory
 
 

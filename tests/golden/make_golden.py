@@ -15,6 +15,11 @@ What is captured:
                     Mesh.compute_face_normals on a displaced mesh (util/mesh.py:87-92),
                     models.compute_fn (util/models.py:5-10) and models.vertex_updating (:31-44)
 
+  noise_<name>.npz  the numpy halves of the two preprocess scripts, which need no MeshLab: preprocess/noisemaker.py:60-73
+                    (``edge_based_scaling`` :32-36 + ``gausian_noise`` :38-42 between ``Mesh()`` / ``Mesh.save`` round trips)
+                    and preprocess/preprocess.py:56-78 (rescale of the saved triplet) -- input OBJ texts and the OBJ texts
+                    the reference's functions leave behind (``python tests/golden/make_golden.py noise`` writes only these)
+
 ``pymeshlab`` is stubbed at import (util/loss.py:4; only used at :279-284).
 ``util/networks.py`` / ``util/datamaker.py`` cannot be imported (torch_geometric absent):
 the GCN stack has no golden vectors -> "parity unpinned" for it (see oracle/README.md).
@@ -180,5 +185,68 @@ def main():
               "bnf5", out["bnf5"], "pos_norm", out["pos_norm"], "mad", out["mad"])
 
 
+def _import_ref_script(name):
+    """preprocess/<name>.py of the reference as a module (its ``import pymeshlab`` hits the stub above; nothing of it is
+    called: the MeshLab filters are the part that cannot run here)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF, "preprocess", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def noise_golden():
+    nm = _import_ref_script("noisemaker")
+    meshes = {
+        "ico2": synth.icosphere(2),
+        "grid7x5": synth.open_grid(7, 5),
+        "cube3": synth.cube_cad(3),
+    }
+    tmp = tempfile.mkdtemp()
+    rd = lambda p: np.frombuffer(open(p).read().encode(), dtype=np.uint8)
+    for k, (name, (vs, faces)) in enumerate(meshes.items()):
+        out = {}
+        level = (0.2, 0.35, 0.1)[k]
+        # -------- noisemaker.py:60-73.  Input: what MeshLab's normalize + save would leave (any mesh in a unit box will do)
+        lo, hi = vs.min(0), vs.max(0)
+        pre = (vs - 0.5 * (lo + hi)) / float((hi - lo).max()) * (1.0, 0.731, 2.4)[k]
+        g_file, n_file = os.path.join(tmp, name + "_gt.obj"), os.path.join(tmp, name + "_noise.obj")
+        write_obj(g_file, pre, faces)
+        out["pre_text"] = rd(g_file)
+        g_mesh = RefMesh(g_file)
+        g_mesh = nm.edge_based_scaling(g_mesh)
+        g_mesh.compute_face_normals()
+        g_mesh.save(g_file)
+        n_mesh = RefMesh(g_file)
+        n_mesh = nm.gausian_noise(n_mesh, level)
+        n_mesh.compute_face_normals()
+        n_mesh.save(n_file)
+        out.update(level=np.float64(level), gt_text=rd(g_file), noise_text=rd(n_file), noise_vs=n_mesh.vs, gt_vs=g_mesh.vs,
+                   mad=np.float64(RefLoss.mad(n_mesh.fn, g_mesh.fn)))
+        # -------- preprocess.py:56-78 (its body past the MeshLab calls, statement by statement).  Input: three saved layers
+        rng = np.random.default_rng(99 + k)
+        s_file = os.path.join(tmp, name + "_smooth.obj")
+        write_obj(n_file, pre * 3.7 + 0.02 * rng.standard_normal(pre.shape), faces)
+        write_obj(s_file, pre * 3.7, faces)
+        write_obj(g_file, pre * 3.7 + 0.001, faces)
+        out.update(p_noise_in=rd(n_file), p_smooth_in=rd(s_file), p_gt_in=rd(g_file))
+        n2, s2, g2 = RefMesh(n_file), RefMesh(s_file), RefMesh(g_file)
+        edge_vec = n2.vs[n2.edges][:, 0, :] - n2.vs[n2.edges][:, 1, :]
+        ave_len = np.sum(np.linalg.norm(edge_vec, axis=1)) / n2.edges.shape[0]
+        n2.vs /= ave_len
+        s2.vs /= ave_len
+        n2.save(n_file)
+        s2.save(s_file)
+        g2.vs /= ave_len
+        g2.save(g_file)
+        out.update(p_noise_out=rd(n_file), p_smooth_out=rd(s_file), p_gt_out=rd(g_file))
+        np.savez_compressed(os.path.join(HERE, "noise_%s.npz" % name), **out)
+        print("noise", name, "level", level, "mad", out["mad"])
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["noise"]:
+        noise_golden()
+    else:
+        main()
+        noise_golden()

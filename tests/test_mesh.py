@@ -128,3 +128,35 @@ def test_laplacian_smooth_follows_the_published_vcglib_rule():
     assert len(synth.border_edges(fi)) == 0
     assert np.array_equal(synth.laplacian_smooth(mi.vs, mi.vv_ptr, mi.vv_idx, steps=3, faces=fi),
                           synth.laplacian_smooth(mi.vs, mi.vv_ptr, mi.vv_idx, steps=3))
+
+
+@pytest.mark.parametrize("name", ["ico2", "grid7x5", "cube3"])
+def test_preprocess_numpy_halves_match_reference_golden(golden_dir, name, tmp_path):
+    """SURVEY 8 f3, the half that needs no MeshLab, pinned to what the reference's own functions write
+    (tests/golden/make_golden.py::noise_golden runs preprocess/noisemaker.py:32-42,60-73 and the body of
+    preprocess/preprocess.py:56-78): the OBJ files come out byte for byte."""
+    from dual_dmp_amd import preprocess
+    from dual_dmp_amd.loss import mad
+    g = np.load(os.path.join(golden_dir, "noise_%s.npz" % name))
+    g_file, n_file, s_file = (str(tmp_path / (name + "_%s.obj" % k)) for k in ("gt", "noise", "smooth"))
+    # noisemaker.py: pre-saved ground truth -> rescaled ground truth, noisy mesh
+    open(g_file, "wb").write(g["pre_text"].tobytes())
+    gt, noisy = preprocess.rescale_and_noise(g_file, n_file, float(g["level"]))
+    assert open(g_file, "rb").read() == g["gt_text"].tobytes()
+    assert open(n_file, "rb").read() == g["noise_text"].tobytes()
+    np.testing.assert_allclose(noisy.vs, g["noise_vs"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(gt.vs, g["gt_vs"], rtol=0, atol=1e-15)
+    assert abs(mad(noisy.fn, gt.fn) - float(g["mad"])) < 1e-9                 # the figure noisemaker.py:79-80 prints
+    # preprocess.py: three normalised layers -> divided by the noisy mesh's mean edge length
+    for f, k in ((n_file, "p_noise_in"), (s_file, "p_smooth_in"), (g_file, "p_gt_in")):
+        open(f, "wb").write(g[k].tobytes())
+    preprocess.rescale_saved(n_file, s_file, g_file)
+    for f, k in ((n_file, "p_noise_out"), (s_file, "p_smooth_out"), (g_file, "p_gt_out")):
+        assert open(f, "rb").read() == g[k].tobytes(), k
+    # ... and without a ground truth (preprocess.py:61-65)
+    for f, k in ((n_file, "p_noise_in"), (s_file, "p_smooth_in")):
+        open(f, "wb").write(g[k].tobytes())
+    os.remove(g_file)
+    out = preprocess.rescale_saved(n_file, s_file, g_file)
+    assert out[0] is None and open(n_file, "rb").read() == g["p_noise_out"].tobytes()
+    assert open(s_file, "rb").read() == g["p_smooth_out"].tobytes()
