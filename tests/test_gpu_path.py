@@ -502,6 +502,69 @@ def test_training_free_running_within_reference_noise_floor(dev, oracle, bnfloop
         assert abs(loss - l64) / l64 <= fac * floor_l + 1e-5, s
 
 
+def test_long_horizon_mad_matches_oracle_fixture(dev, oracle, golden_dir):
+    """north_star: "reproduce its MAD score".  The reference's learning loop (main.py:86-149: 150 iterations across the BNF
+    gate at 101, MAD of the predicted positions' face normals against the ground truth every 10 epochs, :117-127) on a
+    320-face mesh from five weight seeds; the oracle's MADs are a committed fixture (tests/golden/make_mad_fixture.py ->
+    mad_oracle_ico2.npz: its float32 run = the reference arithmetic, and its float64 run of the same seeds).  Adam makes the
+    iteration chaotic, so what can be asserted is the statistic the reference reports, against the oracle's own noise floor
+    nf = rms over seeds of |MAD_f32 - MAD_f64| (0.30 deg at the end of the run):
+      per seed    |MAD_hip - MAD_oracle_f32| <= 3 nf + 0.1 at every evaluation from epoch 50 on
+      over seeds  |mean MAD_hip - mean MAD_oracle_f32| <= 1.5 nf at the end, and the HIP mean denoises as far as the oracle's
+                  (the noisy input has 18.1 deg)."""
+    import zlib
+    from dual_dmp_amd import synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.mesh import Mesh
+    from dual_dmp_amd.loss import mad
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    from dual_dmp_amd.trainer import FusedTrainer
+    fx = np.load(os.path.join(golden_dir, "mad_oracle_ico2.npz"))
+    iters, every = int(fx["iters"]), int(fx["every"])
+    v, f = synth.icosphere(2)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+
+    def mad_of(pos):
+        o = Mesh.__new__(Mesh)
+        o.vs, o.faces = np.asarray(pos, dtype=np.float64), noisy.faces
+        Mesh.compute_face_normals(o)
+        return float(mad(o.fn, gt.fn))
+
+    def crc(sd):
+        c = 0
+        for k in sorted(sd):
+            c = zlib.crc32(sd[k].detach().cpu().numpy().tobytes(), c)
+        return c
+
+    assert abs(mad_of(noisy.vs) - float(fx["noisy_mad"])) < 1e-9
+    hip = []
+    for seed, want in zip(fx["seeds"].tolist(), fx["weights_crc"].tolist()):
+        torch.manual_seed(seed)
+        sd_p, sd_n = oracle.PosNetRef().state_dict(), oracle.NormalNetRef().state_dict()
+        assert [crc(sd_p), crc(sd_n)] == want, "the fixture's initial weights are not reproduced by this torch build"
+        posnet, normnet = PosNet(dev), NormalNet(dev)
+        posnet.load_state_dict(sd_p)
+        normnet.load_state_dict(sd_n)
+        data = dataset_from_meshes(noisy, smooth)
+        data.to(dev)
+        tr = FusedTrainer(posnet, normnet, data, noisy)
+        row = []
+        for ep in range(1, iters + 1):
+            tr.step()
+            if ep % every == 0:
+                row.append(mad_of(tr.pos.cpu().numpy()))
+        hip.append(row)
+    hip, o32, o64 = np.array(hip), fx["mad_f32"], fx["mad_f64"]
+    print("MAD at the end: hip %s | oracle f32 %s | oracle f64 %s" % (np.round(hip[:, -1], 3), np.round(o32[:, -1], 3),
+                                                                    np.round(o64[:, -1], 3)))
+    nf = float(np.sqrt(np.mean((o32[:, -1] - o64[:, -1]) ** 2)))
+    assert 0.05 < nf < 1.0
+    k0 = 50 // every - 1
+    assert np.abs(hip[:, k0:] - o32[:, k0:]).max() <= 3.0 * nf + 0.1, np.abs(hip[:, k0:] - o32[:, k0:]).max()
+    assert abs(hip[:, -1].mean() - o32[:, -1].mean()) <= 1.5 * nf, (hip[:, -1].mean(), o32[:, -1].mean())
+    assert hip[:, -1].mean() < 0.5 * float(fx["noisy_mad"])
+
+
 def test_graph_replay_is_bit_identical_to_eager(dev):
     """The hipGraph-replayed iteration (device-side Adam step count, one captured graph per BNF gate value) and
     the two-stream iteration (PosNet beside NormalNet) launch the same kernels on the same buffers: losses,
