@@ -69,6 +69,9 @@ def parse_args(argv=None):
                          "slower than 150 s cuts them to 1)")
     ap.add_argument("--irregular", type=int, default=1,
                     help="1: also time the step on the same mesh after random edge flips (irregular valence), outside the timed region")
+    ap.add_argument("--gate-open", type=int, default=1,
+                    help="1 (default): warm-up and timed iterations run at epochs > 100, BNF gate open (main.py:101-102), as 900 of the "
+                         "reference's 1000 iterations do; 0: epochs 1.. (gate closed: this build then skips the BNF backward)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--extras", type=int, default=1,
                     help="1: also measure (outside the timed region) gate-open iterations, a randomly numbered mesh and the eval block")
@@ -241,9 +244,9 @@ def cpu_baseline(sample_faces, target_faces, iters=3, f64_truth=False):
 def family_table(summary, steps):
     fam = {}
     for (name, key), a in summary.items():
-        f = fam.setdefault(name, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
-        for k in ("calls", "ms", "bytes", "flops"):
-            f[k] += a[k] / steps
+        f = fam.setdefault(name, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0, bytes8d=0.0))
+        for k in ("calls", "ms", "bytes", "flops", "bytes8d"):
+            f[k] += a.get(k, 0.0) / steps
     return fam
 
 
@@ -292,9 +295,23 @@ def pmc_traffic(name, dtype, launches_per_step):
     return round(tot_b / iters / launches_per_step), os.path.basename(files[-1])
 
 
+def survey_fields(f):
+    """The same family against SURVEY.md 8d's byte count (gather: every row read once + written once + CSR arrays; GEMM:
+    N (C_in + C_out) s per call): `achieved` / `frac` above count every operand stream the fused forms really read."""
+    ms, b8 = f["ms"], f.get("bytes8d", 0.0)
+    if not (ms > 0 and b8 > 0):
+        return {}
+    g8 = b8 / (ms * 1e-3) / 1e9
+    return {"frac_survey_8d": round(g8 / HBM_PEAK_GBS, 4), "achieved_survey_8d_GBs": round(g8, 1),
+            "survey_8d_bytes_per_step": round(b8),
+            "survey_8d_what": "SURVEY.md 8d's algorithmic bytes (no extra operand streams of the fused forms) / the same launch time / 8 TB/s"}
+
+
 def roofline_obj(name, f, dtype):
     ms = f["ms"]
     tb, tsrc = pmc_traffic(name, dtype, f["calls"])
+    tnote = None if tb is None else ("builder lease: the committed rocprofv3 --pmc passes of this command on these kernel sources "
+                                     "(hash-checked), not counters of this run")
     if name.startswith("gemm"):
         from dual_dmp_amd import ops
         mode = ops.get_gemm_mode()
@@ -320,16 +337,19 @@ def roofline_obj(name, f, dtype):
         first, other = (hbm, mfma) if hbm["frac"] > mfma["frac"] else (mfma, hbm)
         out = {"kernel": name}
         out.update(first)
-        out.update({"traffic": tb, "traffic_source": tsrc, "other_roofline": other,
+        out.update(survey_fields(f))
+        out.update({"traffic": tb, "traffic_source": tsrc, "traffic_measured_on": tnote, "other_roofline": other,
                     "algorithmic_TFLOPs": round(f32_eq, 2), "frac_of_f32_mfma_peak": round(f32_eq / MFMA_F32_PEAK_TF, 4),
                     "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
                     "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1)), "note": note})
         return out
     ach = f["bytes"] / (ms * 1e-3) / 1e9
-    return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tb, "traffic_source": tsrc,
-            "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
-            "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
+    out = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tb, "traffic_source": tsrc, "traffic_measured_on": tnote,
+           "ms_per_step": round(ms, 3), "launches_per_step": f["calls"],
+           "alg_bytes_per_launch": round(f["bytes"] / max(f["calls"], 1))}
+    out.update(survey_fields(f))
+    return out
 
 
 def gather_ceilings(dev, sizes, dtype, copy_gbs=None):
@@ -433,7 +453,9 @@ def parity_object(hip, ref):
            "mad_delta_deg_of_the_predicted_normals": abs(mn_h - mn_o),
            "what": "iteration 1 of the HIP path (the timed configuration: hipGraph + two streams; its first iteration runs eagerly) "
                    "vs the oracle's float32 CPU iteration, identical initial weights, same mesh; MAD of the face normals of the "
-                   "predicted positions vs ground truth"}
+                   "predicted positions vs ground truth.  The oracle's losses / mesh tables / MAD are pinned to vectors captured from "
+                   "the reference; its GCN stack (GCNConv, both nets, the step) is the RESTATED published algorithm of "
+                   "torch-geometric 2.2.0, UNPINNED: PyG is absent from this image and the reference holds no tests for it"}
     # the distribution behind the two maxima (per row: largest component difference).  NormalNet's head divides by the length of
     # its tanh output: a face whose un-normalised vector is short amplifies the float32 noise of BOTH sides by 1 / length, and
     # the oracle's own CPU run is not bit-reproducible (threaded index_add) -- the maximum over 1M faces moves between runs
@@ -570,11 +592,18 @@ def main():
         if multi:
             from dual_dmp_amd.dist import make_distributed_trainer
             nets = (PosNet(dev, dtype=fdt), NormalNet(dev, dtype=fdt))
-            return make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop, nets=nets)
-        posnet, normnet = PosNet(dev, dtype=fdt), NormalNet(dev, dtype=fdt)
-        data.to(dev)
-        return FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph),
-                            overlap=bool(args.overlap))
+            t_ = make_distributed_trainer(noisy, smooth, data, dev, rank, world, bnfloop=args.bnfloop, nets=nets)
+        else:
+            posnet, normnet = PosNet(dev, dtype=fdt), NormalNet(dev, dtype=fdt)
+            data.to(dev)
+            t_ = FusedTrainer(posnet, normnet, data, noisy, bnfloop=args.bnfloop, use_graph=bool(args.graph),
+                              overlap=bool(args.overlap))
+        # The timed iterations of EVERY leg run with the BNF gate OPEN (main.py:101-102: epochs > 100 -- 900 of the reference's
+        # 1000 iterations): with the gate closed this build skips the BNF backward that the reference still differentiates
+        # (times 0.0), so gate-closed iterations do less work than the reference's; that figure is reported beside it.
+        if args.gate_open and hasattr(t_, "bnf_start_epoch"):
+            t_.epoch = max(t_.epoch, t_.bnf_start_epoch)
+        return t_
 
     t_setup = time.perf_counter()
     gt, noisy, smooth, data = build_case(args.faces, args.order)
@@ -582,6 +611,7 @@ def main():
     tr = make_trainer(noisy, smooth, data)
     barrier = tr.barrier if multi else (lambda: None)
     setup_s = time.perf_counter() - t_setup
+    gate_open = bool(args.gate_open) and hasattr(tr, "bnf_start_epoch")
 
     def sync():
         barrier()
@@ -637,12 +667,22 @@ def main():
             mad_dev = ev.mad(tr.pos)                   # face normals + MAD on the device, one scalar back (main.py:117-123)
         out["eval_block_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         out["mad_deg"]["device_evaluator"] = round(mad_dev, 4)
-        # iterations 101..: the BNF gate is open (main.py:101-102), its backward runs
-        tr.epoch = max(tr.epoch, tr.bnf_start_epoch)
+        # the other gate state (outside the timed region): epochs <= 100, k4 * fn_bnf_loss * 0.0 -- no BNF backward here
+        ep_keep = tr.epoch
+        tr.epoch = 0 if gate_open else max(tr.epoch, tr.bnf_start_epoch)
         for _ in range(3):
             tr.step().item()
-        out["gate_open_ms_per_step"] = round(timed_steps(tr, max(5, args.steps // 2), sync)[0], 3)
-        out["gate_open_note"] = "epochs > %d: k4 * fn_bnf_loss takes part in the backward (bnfloop=%d)" % (tr.bnf_start_epoch, args.bnfloop)
+        other_ms = round(timed_steps(tr, max(5, args.steps // 2), sync)[0], 3)
+        tr.epoch = ep_keep
+        tr.step().item()
+        open_ms, closed_ms = (round(ms_per_step, 3), other_ms) if gate_open else (other_ms, round(ms_per_step, 3))
+        out["gate_open_ms_per_step"], out["gate_closed_ms_per_step"] = open_ms, closed_ms
+        out["reference_run_blend_ms_per_step"] = round(0.1 * closed_ms + 0.9 * open_ms, 3)
+        out["gate_note"] = ("value / ms_per_step are gate-%s iterations.  epochs > %d: k4 * fn_bnf_loss takes part in the backward "
+                            "(bnfloop=%d); epochs <= %d: the reference multiplies it by 0.0 and still differentiates it "
+                            "(main.py:101-107), this build skips that backward; blend = 100 closed + 900 open iterations of the "
+                            "reference's default --iter 1000" % ("OPEN" if gate_open else "CLOSED", tr.bnf_start_epoch, args.bnfloop,
+                                                                 tr.bnf_start_epoch))
 
     # ---- profiled pass (separate from the timed region): HIP events around every launch
     def profiled_pass(tr, dtype_name, out):
@@ -666,7 +706,7 @@ def main():
         fam = family_table(summ, args.profile_steps)
         if rank == 0:
             # the three GEMM forms (forward NT, dgrad NN, wgrad TN) are one kernel family on one roofline
-            gem = dict(calls=0, ms=0.0, bytes=0.0, flops=0.0)
+            gem = dict(calls=0, ms=0.0, bytes=0.0, flops=0.0, bytes8d=0.0)
             for k_, f_ in fam.items():
                 if k_.startswith("gemm"):
                     for kk in gem:
@@ -800,7 +840,7 @@ def main():
             return 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         torch_copy_gbs = copy_rate(lambda: dst.copy_(src))
         probe = {"plain": copy_rate(lambda: ops.copy_probe(src, dst, 0)), "nontemporal": copy_rate(lambda: ops.copy_probe(src, dst, 1))}
-        copy_gbs = max(probe.values())
+        copy_gbs = max(probe.values())        # (raised below to the best figure of the slab-pattern copy: ADVICE round 5)
         # ... and in the gather's access pattern (64-row chunks walked one 128-byte slab at a time) at the step's row widths
         slab = {}
         for Cw in (512, 256, 128, 64, 32):
@@ -819,7 +859,10 @@ def main():
                               "slab_pattern_copy_GBs_by_row_width": slab,
                               "slab_pattern_what": "ddmp_copy_probe_rows: 2 GiB of float32 rows of that width copied in the gather's own "
                                                    "access pattern (64-row chunks, one 128-byte slab at a time): the pattern's ceiling",
-                              "what": "2 GiB read + 2 GiB written; frac_of_device_copy below divides by the better ddmp_copy_probe figure"}
+                              "what": "2 GiB read + 2 GiB written; frac_of_device_copy below divides by the BEST copy measured here "
+                                      "(max over ddmp_copy_probe plain / nontemporal and the slab-pattern copy at any width)"}
+        copy_gbs = max([copy_gbs] + list(slab.values()))
+        out["device_copy"]["best_GBs"] = round(copy_gbs, 1)
         del src, dst
         torch.cuda.empty_cache()
         for r_ in (roof, roof_gather) + ((bf16.get("roofline"), bf16.get("roofline_gather")) if bf16 else ()):
@@ -869,11 +912,18 @@ def main():
             6: "bf16x6 split MFMA, f32 accumulate (f32-class accuracy)", 3: "bf16x3 split MFMA", 0: "f32-input MFMA",
             13: "f16x3 split MFMA on scaled operands, f32 accumulate (f32-class accuracy; bf16x6 in the narrow layers)",
         }[ops.get_gemm_mode()]
+        dtype_label = {("f32", 13): "f32 (f16x3 split-MFMA GEMMs, f32 accumulate)", ("f32", 6): "f32 (bf16x6 split-MFMA GEMMs, f32 accumulate)",
+                       ("f32", 3): "f32 (bf16x3 split-MFMA GEMMs)", ("f32", 0): "f32"}.get((args.dtype, ops.get_gemm_mode()),
+                                                                                          "bf16 features (bf16 MFMA, f32 accumulate)")
         line = {
             "metric": "training iters/sec + MAD score, 1M-face mesh @ 1/2/4/8 MI355X",
             "value": round(args.steps / elapsed, 4), "unit": "iters/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "vs_baseline_note": "null: BASELINE.md holds no published number for this metric; the reference's own figures are MADs "
+                                "on its bundled meshes (README.md:57-67), and datasets.zip is absent from the reference tree -- they "
+                                "cannot be reproduced here",
+            "dtype": dtype_label, "data": "synthetic",
             "gemm_arithmetic": arith,
             "config": {"workload": "synthetic torus-grid manifold mesh, %d faces / %d verts, %s features, k=(3,4,4,4,1), "
                                    "bnfloop=%d, %s numbering (BASELINE.json configs[2]%s)"

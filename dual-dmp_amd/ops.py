@@ -52,17 +52,18 @@ class Profiler:
     Off by default: ``ops.PROF = ops.Profiler()`` switches it on."""
 
     def __init__(self):
-        self.records = []          # (name, key, alg_bytes, flops, ev0, ev1)
+        self.records = []          # (name, key, alg_bytes, flops, survey_bytes, ev0, ev1)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, key, b, f, e0, e1 in self.records:
-            a = agg.setdefault((name, key), dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+        for name, key, b, f, b8, e0, e1 in self.records:
+            a = agg.setdefault((name, key), dict(calls=0, ms=0.0, bytes=0.0, flops=0.0, bytes8d=0.0))
             a["calls"] += 1
             a["ms"] += e0.elapsed_time(e1)
             a["bytes"] += b
             a["flops"] += f
+            a["bytes8d"] += b8
         return agg
 
 
@@ -72,8 +73,10 @@ PROF = None
 class _timed:
     __slots__ = ("args", "e0")
 
-    def __init__(self, name, key, alg_bytes=0.0, flops=0.0):
-        self.args = (name, key, alg_bytes, flops)
+    def __init__(self, name, key, alg_bytes=0.0, flops=0.0, survey=None):
+        # survey: SURVEY.md 8d's count for the op (gather: every row read once + written once + CSR; GEMM: N (C_in + C_out) s),
+        # which leaves out the extra operand streams of the fused forms that alg_bytes includes; default = alg_bytes
+        self.args = (name, key, alg_bytes, flops, alg_bytes if survey is None else survey)
 
     def __enter__(self):
         if PROF is not None:
@@ -423,7 +426,7 @@ def spmm_stats(g: Graph, x, out, ref, sums, bias=None, pro=None, slope=SLOPE, bn
     ws = Workspace.get(max(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), L.ddmp_colreduce_workspace_bytes(g.n_rows, C)), x.device)
     es = x.element_size()
     alg = float(es) * (g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows
-    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C, survey=2.0 * g.n_rows * C * es + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows):
         o, keep = _mk_opts(bn, want_bn=True)
         st = L.ddmp_spmm_stats_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(bias), _p(ps), _p(psh), slope,
                                  _p(_chk(ref, torch.float32, "ref")), _p(sums), _p(ws), ws.numel(), _stream(), o)
@@ -440,7 +443,7 @@ def spmm_bnred(g: Graph, x, out, yp, bn4, sums2, slope=SLOPE, bn=None):
     L = _lib.lib()
     ws = Workspace.get(L.ddmp_spmm_bnred_ws_bytes(g.n_rows, C, _dt(x)), x.device)
     alg = 3.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows
-    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C):
+    with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), alg, 2.0 * g.nnz * C, survey=2.0 * g.n_rows * C * x.element_size() + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows):
         o, keep = _mk_opts(bn, want_bn=True)
         st = L.ddmp_spmm_bnred_o(g.handle, _p(x), ldx, _p(out), ldy, C, _dt(x), _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                  _p(bn4[2]), _p(bn4[3]), slope, _p(sums2), _p(ws), ws.numel(), _stream(), o)
@@ -462,7 +465,7 @@ def spmm_bnbwd(g: Graph, dz, yb, bn4, c10, out, slope=SLOPE):
     assert dz.shape[0] >= g.n_cols and yb.shape[0] >= g.n_cols and out.shape[0] >= g.n_rows and yb.shape[1] == C
     es = dz.element_size()
     with _timed("spmm", (C, int(round(g.nnz / max(g.n_rows, 1)))), es * (2.0 * g.n_cols + g.n_rows) * C + 4.0 * g.nnz + 8.0 * g.n_rows,
-                2.0 * g.nnz * C):
+                2.0 * g.nnz * C, survey=2.0 * g.n_rows * C * es + 4.0 * g.nnz + 4.0 * (g.n_rows + 1) + 4.0 * g.n_rows):
         st = _lib.lib().ddmp_spmm_bnbwd(g.handle, _p(dz), lddz, _p(yb), ldyb, _p(out), ldo, C, _dt(dz), _p(bn4[0]),
                                         _p(bn4[1]), _p(c10[0]), _p(c10[1]), slope, _stream())
     check(st, "ddmp_spmm_bnbwd")
@@ -530,7 +533,7 @@ def gemm_nt(a, w, out=None, bias=None, pro=None, slope=SLOPE, n_rows=None, wplan
     L = _lib.lib()
     ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
-    with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_nt", (K, M), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=es * n * (K + M)):
         o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nt_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _dt(a), _p(bias), _p(ps), _p(psh),
                               slope, _p(ws), ws.numel(), _stream(), o)
@@ -557,7 +560,7 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
             nb = (L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)) + 255) // 256 * 256
             sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, M)
             ws = Workspace.get(nb + sb, a.device)
-            with _timed("gemm_nt", (K, M), 2.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+            with _timed("gemm_nt", (K, M), 2.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=2.0 * n * (K + M)):
                 o, keep = _mk_opts(bn, want_bn=True)
                 st = L.ddmp_gemm_nt_stats_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
                                                  _p(sums), _p(ws), nb, ws.data_ptr() + nb, ws.numel() - nb, _stream(), o)
@@ -581,7 +584,7 @@ def gemm_nt_stats(a, w, sums, out=None, bias=None, pro=None, slope=SLOPE, n_rows
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, M)
     ws = Workspace.get(nb + sb, a.device)
     wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
-    with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_nt", (K, M), 4.0 * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=4.0 * n * (K + M)):
         o, keep = _mk_opts(bn, scales, wplanes is not None, want_bn=True, want_scales=True)
         st = L.ddmp_gemm_nt_stats_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, K, M, _p(bias), _p(ps), _p(psh), slope,
                                         _p(sums), _p(wp), nb if wplanes is None else wp.numel(), ws.data_ptr() + nb,
@@ -604,7 +607,7 @@ def gemm_nn(a, w, out=None, n_rows=None, wplanes=None, scales=None):
     L = _lib.lib()
     ws, prep = _wws(wplanes if a.dtype == torch.float32 else None, L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)), a.device)
     es = a.element_size()
-    with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_nn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=es * n * (K + M)):
         o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nn_o(_p(a), lda, _p(w), ldw, _p(out), ldy, n, M, K, _dt(a), _p(ws), ws.numel(), _stream(), o)
     check(st, "ddmp_gemm_nn")
@@ -635,7 +638,7 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
         nb = (L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)) + 255) // 256 * 256
         sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, K)
         ws = Workspace.get(nb + sb, a.device)
-        with _timed("gemm_nn", (M, K), 2.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
+        with _timed("gemm_nn", (M, K), 2.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=2.0 * n * (K + M)):
             o, keep = _mk_opts(bn, want_bn=True)
             st = L.ddmp_gemm_nn_bnred_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                              _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(ws), nb, ws.data_ptr() + nb,
@@ -646,7 +649,7 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
     ws = Workspace.get(nb + sb, a.device)
     wp = ws if wplanes is None else _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), a.device)[0]
-    with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_nn", (M, K), 4.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=4.0 * n * (K + M)):
         o, keep = _mk_opts(bn, scales, wplanes is not None, want_bn=True, want_scales=True)
         st = L.ddmp_gemm_nn_bnred_f32_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
                                         _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(wp), nb if wplanes is None else wp.numel(),
@@ -669,7 +672,7 @@ def gemm_tn(g, z, out=None, pro=None, slope=SLOPE, n_rows=None, scales=None):
     ws = Workspace.get(need, g.device)
     ps, psh = (None, None) if pro is None else pro
     es = g.element_size()
-    with _timed("gemm_tn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_tn", (M, K), es * n * (K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=es * n * (K + M)):
         o, keep = _mk_opts(None, scales, want_scales=True)
         st = L.ddmp_gemm_tn_o(_p(g), ldg, _p(z), ldz, _p(out), ldo, n, M, K, _dt(g), _p(ps), _p(psh), slope, _p(ws),
                               ws.numel(), _stream(), o)
@@ -727,7 +730,7 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplan
         out, ldo = _mat(out, "out", dz)
         L = _lib.lib()
         ws = Workspace.get(L.ddmp_gemm_rows_ws_bytes(K, M, _dt(dz)), dz.device)
-        with _timed("gemm_nn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+        with _timed("gemm_nn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M, survey=2.0 * n * (K + M)):
             st = L.ddmp_gemm_nn_bnbwd_bf16(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                            _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream())
         check(st, "ddmp_gemm_nn_bnbwd_bf16")
@@ -742,7 +745,7 @@ def gemm_nn_bnbwd(dz, yb, w, bn4, c10, out=None, slope=SLOPE, n_rows=None, wplan
     out, ldo = _mat(out, "out")
     L = _lib.lib()
     ws, prep = _wws(wplanes, L.ddmp_gemm_rows_workspace_bytes(K, M), dz.device)
-    with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_nn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M, survey=4.0 * n * (K + M)):
         o, keep = _mk_opts(None, scales, prep, want_scales=True)
         st = L.ddmp_gemm_nn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(w), ldw, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                         _p(c10[0]), _p(c10[1]), slope, _p(ws), ws.numel(), _stream(), o)
@@ -764,7 +767,7 @@ def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=N
         L = _lib.lib()
         ws = Workspace.get(L.ddmp_gemm_tn_ws_bytes(n, M, K, _dt(dz)), dz.device)
         ps, psh = (None, None) if pro is None else pro
-        with _timed("gemm_tn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+        with _timed("gemm_tn", (M, K), 2.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M, survey=2.0 * n * (K + M)):
             st = L.ddmp_gemm_tn_bnbwd_bf16(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                            _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream())
         check(st, "ddmp_gemm_tn_bnbwd_bf16")
@@ -780,7 +783,7 @@ def gemm_tn_bnbwd(dz, yb, z, bn4, c10, out=None, pro=None, slope=SLOPE, n_rows=N
     L = _lib.lib()
     ws = Workspace.get(L.ddmp_gemm_tn_workspace_bytes(n, M, K), dz.device)
     ps, psh = (None, None) if pro is None else pro
-    with _timed("gemm_tn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M):
+    with _timed("gemm_tn", (M, K), 4.0 * n * (K + 2 * M) + 4.0 * K * M, 2.0 * n * K * M, survey=4.0 * n * (K + M)):
         o, keep = _mk_opts(None, scales, want_scales=True)
         st = L.ddmp_gemm_tn_bnbwd_f32_o(_p(dz), lddz, _p(yb), ldyb, _p(z), ldz, _p(out), ldo, n, M, K, _p(bn4[0]), _p(bn4[1]),
                                         _p(c10[0]), _p(c10[1]), _p(ps), _p(psh), slope, _p(ws), ws.numel(), _stream(), o)
