@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -41,3 +43,18 @@ def load_oracle():
 @pytest.fixture(scope="session")
 def oracle():
     return load_oracle()
+
+
+def pytest_collection_finish(session):
+    """The two 144k-face teacher-forced comparisons (tests/test_gpu_path.py) need 50-100 s of CPU oracle each while the GPU idles:
+    when they are selected, their oracle halves start now in two worker processes and run beside the rest of the suite."""
+    if any("teacher_forced" in it.nodeid and "_at_144k" in it.nodeid for it in session.items) \
+            and os.environ.get("DDMP_TEST_ORACLE_WORKERS", "1") != "0" and (os.cpu_count() or 1) >= 24:
+        import oracle_jobs
+        oracle_jobs.start_big_jobs()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    mod = sys.modules.get("oracle_jobs")
+    if mod is not None:
+        mod.shutdown()

@@ -273,13 +273,32 @@ SWITCHES = [{"DDMP_SPMM_PATCH": "1"}, {"DDMP_SPMM_PATCH": "0"}, {"DDMP_SPMM_PATC
             {"DDMP_SPMM_PATCH": "1", "DDMP_SPMM_PATCH_NE": "0"}]
 
 
+_SWITCH_RUNS = {}
+
+
+def _switch_runs():
+    """All five switched re-runs are started TOGETHER, by whichever of the parametrised tests below runs first (each is a pytest
+    process of ~60 s, most of it start-up and host-side mesh building: one after the other they were 300 of the suite's 810 s)."""
+    if not _SWITCH_RUNS:
+        for env in SWITCHES:
+            e = dict(os.environ)
+            e.update(env)
+            key = tuple(sorted(env.items()))
+            _SWITCH_RUNS[key] = subprocess.Popen(
+                [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not under_switch",
+                 "-p", "no:cacheprovider"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=os.path.dirname(HERE))
+    return _SWITCH_RUNS
+
+
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_irregular_graphs_under_switch(env):
     """The tests above once more, in their own process, with the gather's kernel selection switched (read once per process)."""
     if any(k.startswith("DDMP_SPMM") for k in os.environ):
         pytest.skip("already inside a switched run")
-    e = dict(os.environ)
-    e.update(env)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "not under_switch",
-                        "-p", "no:cacheprovider"], env=e, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, (env, r.stdout[-3000:], r.stderr[-2000:])
+    proc = _switch_runs()[tuple(sorted(env.items()))]
+    try:
+        out, err = proc.communicate(timeout=1500)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        raise
+    assert proc.returncode == 0, (env, out[-3000:], err[-2000:])

@@ -146,30 +146,11 @@ def test_non_default_ltypes_match_reference_golden(dev, golden_dir, name):
 
 
 # ------------------------------------------------------------------------------------ nets
-def _flipped(vf, hub):
-    from dual_dmp_amd import synth
-    v, f = vf
-    f = synth.flip_edges(v, f, rounds=10, seed=1)
-    f = synth.add_hub(v, f, hub, 24)
-    hist = synth.valence_histogram(f, len(v))
-    assert len(hist) - 1 == 24 and hist[3] > 0 and hist[10:].sum() > 1, hist
-    return v, f
+import oracle_jobs as OJ  # noqa: E402  (tests/oracle_jobs.py: mesh cases + the oracle half of the teacher-forced comparison)
 
 
 def _case(dev, which="ico3"):
-    from dual_dmp_amd import synth
-    from dual_dmp_amd.datamaker import dataset_from_meshes
-    v, f = {"ico3": lambda: synth.icosphere(3), "grid": lambda: synth.open_grid(12, 9),
-            "cad33": lambda: synth.cube_cad(33),         # 13,068 faces: the fandisk stand-in (README.md:57 of the reference)
-            "grid24": lambda: synth.open_grid(24, 17),
-            "torus48k": lambda: synth.torus(220, 110),   # 48,400 faces / 24,200 verts: row-panel routes on both graphs
-            "torus144k": lambda: synth.torus(380, 190),  # 144,400 faces / 72,200 verts: every bench route is on
-            # irregular valence (round 5): random edge flips (valence 3 ... 12+) and a valence-24 hub
-            "flip": lambda: _flipped(synth.torus(30, 14), 17),
-            "flip144k": lambda: _flipped(synth.torus(380, 190), 1000)}[which]()
-    v, f = synth.permute_vertices(v, f, 3)
-    gt, noisy, smooth = synth.make_triplet(v, f)
-    return gt, noisy, smooth, dataset_from_meshes(noisy, smooth)
+    return OJ.case(which)
 
 
 @pytest.mark.parametrize("mesh", ["grid", "flip"])
@@ -283,49 +264,7 @@ def test_fused_net_follows_nn_module_semantics(dev, oracle):
     assert "bogus" in bad.unexpected_keys and "conv1.lin.weight" in bad.missing_keys
 
 
-def _oracle_nets(oracle, sd_pos, sd_norm, dtype=torch.float32):
-    posnet, normnet = oracle.PosNetRef(), oracle.NormalNetRef()
-    posnet.load_state_dict(sd_pos)
-    normnet.load_state_dict(sd_norm)
-    if dtype == torch.float64:
-        posnet.double()
-        normnet.double()
-    return posnet, normnet
-
-
-def _oracle_inputs(oracle, noisy, smooth, dtype):
-    odata = oracle.OracleDataset(noisy, smooth)
-    mesh = noisy
-    if dtype == torch.float64:
-        for k in ("z1", "z2", "x_pos"):
-            setattr(odata, k, getattr(odata, k).double())
-        mesh = types.SimpleNamespace(vs=noisy.vs, fn=noisy.fn, faces=noisy.faces, f2f=noisy.f2f,
-                                     v2v_mat=noisy.v2v_mat.double(), v_dims=noisy.v_dims.double())
-    return odata, mesh
-
-
-def _oracle_grads(oracle, rp, rn, noisy, smooth, args, epoch, dtype):
-    """Pre-clip gradients of one iteration from the current oracle state, evaluated in `dtype`."""
-    import copy
-    p2, n2 = copy.deepcopy(rp), copy.deepcopy(rn)
-    if dtype == torch.float64:
-        p2.double()
-        n2.double()
-    odata, omesh = _oracle_inputs(oracle, noisy, smooth, dtype)
-    p2.train(); n2.train()
-    p2.zero_grad(); n2.zero_grad()
-    total, _ = oracle.losses(p2(odata), n2(odata), omesh, args, epoch)
-    total.backward()
-    return ({n: p.grad.detach().clone() for n, p in p2.named_parameters()},
-            {n: p.grad.detach().clone() for n, p in n2.named_parameters()})
-
-
-def _snapshot(net, opt):
-    names = {p: n for n, p in net.named_parameters()}
-    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    m = {names[p]: st["exp_avg"].clone() for p, st in opt.state.items()}
-    v = {names[p]: st["exp_avg_sq"].clone() for p, st in opt.state.items()}
-    return sd, m, v
+_oracle_nets, _oracle_inputs, _oracle_grads, _snapshot = OJ.oracle_nets, OJ.oracle_inputs, OJ.oracle_grads, OJ.snapshot
 
 
 DEFAULT_K = (3.0, 4.0, 4.0, 4.0, 1.0)                    # main.py:22-26
@@ -391,13 +330,10 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect
     from dual_dmp_amd.networks import PosNet, NormalNet
     from dual_dmp_amd.trainer import FusedTrainer
     gt, noisy, smooth, data = _case(dev, which)
-    torch.manual_seed(11)
-    sd_pos, sd_norm = oracle.PosNetRef().state_dict(), oracle.NormalNetRef().state_dict()
-    rp, rn = _oracle_nets(oracle, sd_pos, sd_norm)
-    odata, omesh = _oracle_inputs(oracle, noisy, smooth, torch.float32)
-    args = oracle.StepArgs(bnfloop=bnfloop, k1=k[0], k2=k[1], k3=k[2], k4=k[3], k5=k[4])
-    op = torch.optim.Adam(rp.parameters(), lr=args.pos_lr)
-    on = torch.optim.Adam(rn.parameters(), lr=args.norm_lr)
+    # the oracle's half (tests/oracle_jobs.py): from the worker process started with the session for the two 144k-face cases
+    recs = OJ.big_job(which) if OJ.BIG_JOBS.get(which) == (which, k, bnfloop, ep0, iters, check_at) else None
+    if recs is None:
+        recs = OJ.teacher_forced_oracle(which, k, bnfloop, ep0, iters, check_at, meshes=(gt, noisy, smooth, data))
     posnet, normnet = PosNet(dev), NormalNet(dev)
     tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=bnfloop, k=k)
     if expect_fused:
@@ -413,19 +349,15 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect
             assert all(ops.gemm_nn_bnred_supported(eng.layout.cout[l], eng.layout.cin_p[l], eng.n_rows)
                        for l in range(1, 12) if not eng.agg_first[l])
             assert eng._prep_weights
-    for it in range(1, iters + 1):
-        if it in check_at:
-            for which, (net, ref, opt) in enumerate(((posnet, rp, op), (normnet, rn, on))):
-                sd, m, v = _snapshot(ref, opt)
-                net.load_state_dict(sd)
-                tr.load_adam_state(which, m, v, it - 1)
-            tr.epoch = ep0 + it - 1
-            before = [posnet.arena.detach().clone(), normnet.arena.detach().clone()]
-            g32 = _oracle_grads(oracle, rp, rn, noisy, smooth, args, ep0 + it, torch.float32)
-            g64 = _oracle_grads(oracle, rp, rn, noisy, smooth, args, ep0 + it, torch.float64)
-        ref_loss, ref_pos, ref_norm, parts = oracle.train_step(rp, rn, op, on, odata, omesh, args, ep0 + it)
-        if it not in check_at:
-            continue
+    for it in check_at:
+        rec = recs[it]
+        for w, net in enumerate((posnet, normnet)):
+            sd, m, v = rec["state"][w]
+            net.load_state_dict(sd)
+            tr.load_adam_state(w, m, v, it - 1)
+        tr.epoch = ep0 + it - 1
+        g32, g64 = rec["g32"], rec["g64"]
+        ref_loss, ref_pos, ref_norm, parts = rec["loss"], rec["pos"], rec["norm"], rec["parts"]
         loss = tr.step().item()
         assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss), (it, loss, ref_loss)
         lb = tr.lossbuf.cpu().numpy()
@@ -449,13 +381,13 @@ def _teacher_forced(dev, oracle, which, k, bnfloop, ep0, iters, check_at, expect
         assert abs(float(tr.sumsq.item()) ** 0.5 - tot64) <= 1e-3 * tot64
         # the update: Adam's first iterations are sign-like (|dp| ~ lr), so a rounding-level sign flip of a
         # near-zero gradient moves that one weight by 2*lr; bound the fraction of such weights
-        for net, ref, b4 in ((posnet, rp, before[0]), (normnet, rn, before[1])):
+        for net, after in ((posnet, rec["after"][0]), (normnet, rec["after"][1])):
             views = net.named_views()
             bad = tot = 0
-            for n, p in ref.named_parameters():
+            for n, p in after.items():
                 if n.startswith("conv") and n.endswith(".bias"):
                     continue
-                d = (views[n].cpu() - p.detach()).abs()
+                d = (views[n].cpu() - p).abs()
                 bad += int((d > 1e-3).sum())
                 tot += d.numel()
             assert bad <= 2e-3 * tot, (it, bad, tot)
