@@ -33,6 +33,8 @@ def run(graph, overlap, iters=200):
 
 if os.environ.get("MODE") == "trace":
     print(run(False, False, iters=3))
+elif os.environ.get("MODE") == "trace_graph":                      # one replayed hipGraph per iteration, two streams
+    print(run(True, os.environ.get("STREAMS", "2") == "2", iters=20))
 else:
     print("%d faces / %d verts" % (len(f), len(v)))
     for graph, overlap in ((False, False), (True, False), (True, True)):
