@@ -771,16 +771,22 @@ class DistributedTrainer:
                           "eagerly (set DDMP_DIST_GRAPH_PEERS=1 to capture anyway)" % backend.world_size)
             self.use_graph = False
         if self.use_graph:
-            # ONE communicator on ONE stream under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1
-            # (tests/test_gpu_multi.py): the captured iteration replays correctly with one communicator; with a second
-            # communicator in the same capture it ends in a SIGSEGV (two streams) or never returns (one stream).
-            backend_pos = None
+            # ONE communicator under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1 (tests/test_gpu_multi.py): the
+            # captured iteration replays correctly with one communicator; with a SECOND communicator in the same capture it ends
+            # in a SIGSEGV (two streams) or never returns (one stream).  Round 6: the stream is forked INSIDE the capture and both
+            # nets use the one communicator (RCCL serialises a communicator's operations in issue order, which is the same on
+            # every rank: PosNet's forward, NormalNet's forward, ...) -- DDMP_DIST_GRAPH_STREAMS=1 keeps the single stream.
+            # With peers the two-stream form is opt-in (DDMP_DIST_GRAPH_STREAMS=2): like the capture itself it has only run on
+            # a one-rank loopback communicator.
+            want2 = os.environ.get("DDMP_DIST_GRAPH_STREAMS", "2" if backend.world_size == 1 else "1") == "2"
+            backend_pos = backend if want2 else None
         with ctx:
             self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
                        eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
         self._graphs, self._warm = {}, False
         if self.use_graph:
             self.interleaved = False
+            self.peng.async_wgrad = self.neng.async_wgrad = False      # (never a third stream inside the capture)
             self._t_dev = torch.zeros(1, dtype=torch.int32, device=device)
             self._coef = [torch.zeros(2, dtype=torch.float32, device=device) for _ in range(2)]
 
@@ -979,7 +985,7 @@ class DistributedTrainer:
             dpos_loc, dnorm_loc = dpos.index_select(0, self.owned_v), dnorm.index_select(0, self.owned_f)
         if self.two_streams:
             self._fork()
-            if dpos_loc.is_cuda:
+            if dpos_loc.is_cuda and not torch.cuda.is_current_stream_capturing():
                 dpos_loc.record_stream(self._side)               # (allocated on this stream, read on the other)
             with torch.cuda.stream(self._side):                  # PosNet: backward, gradient all-reduce, Adam -- beside NormalNet
                 self.peng.backward(pa, pg, dpos_loc)

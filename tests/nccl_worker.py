@@ -70,9 +70,9 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print("world %d, %s, losses=%s, interleave=%s, native=%s, loopback=%s, captured=%d, healed=%d: %s" % (
+        print("world %d, %s, losses=%s, interleave=%s, native=%s, loopback=%s, captured=%d, streams=%d, healed=%d: %s" % (
             world, kind, losses, os.environ.get("DDMP_DIST_INTERLEAVE", "0"), os.environ.get("DDMP_DIST_NATIVE", "0"),
-            os.environ.get("DDMP_COMM_LOOPBACK", "0"), int(bool(getattr(tr, "_graphs", None))), healed,
+            os.environ.get("DDMP_COMM_LOOPBACK", "0"), int(bool(getattr(tr, "_graphs", None))), 2 if getattr(tr, "two_streams", False) else 1, healed,
             "PARITY" if ok else "FAILED"), flush=True)
     sys.exit(int(verdict.item()))
 

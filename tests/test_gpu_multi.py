@@ -39,4 +39,5 @@ def test_rccl_ranks_match_single_device(kind, losses, interleave, native, stream
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "PARITY" in r.stdout, tail
     if extra.get("DDMP_DIST_GRAPH"):
-        assert "captured=1" in r.stdout, tail
+        # round 6: with DDMP_DIST_STREAMS=1 the capture forks PosNet's stream INSIDE the graph, both nets on the ONE communicator
+        assert "captured=1" in r.stdout and ("streams=%d" % (2 if streams == "1" else 1)) in r.stdout, tail
