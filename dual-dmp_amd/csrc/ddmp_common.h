@@ -171,6 +171,7 @@ struct ddmp_graph {
     int32_t* rowptr;    // device [n_rows + 1]
     int32_t* col;       // device [nnz]
     float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
+    float* dinv_r;      // = dinv + row0: the factor of output row i (row0 > 0: a row SLICE of a local graph, see ddmp_graph_create_csr_rows_host)
     int max_row_nnz;
     // LDS-patch gather (spmm_patch.hip).  Per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR
     // entry, the index of its column in that list.  Selection is PER CHUNK: a chunk whose patch does not fit the kernel's

@@ -129,7 +129,7 @@ extern "C" int ddmp_rcb_order_host(int64_t n, const double* xyz, int leaf, int32
 }
 
 static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
-                        const float* dinv, ddmp_graph** out) {
+                        const float* dinv, ddmp_graph** out, int64_t row0 = 0) {
     ddmp_graph* g = new (std::nothrow) ddmp_graph();
     if (!g) return DDMP_ENOMEM;
     std::memset(g, 0, sizeof(*g));
@@ -147,6 +147,7 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
     if (g->nnz > 0 &&
         (e = hipMemcpy(g->col, col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    g->dinv_r = g->dinv + row0;                                  // output row i is node row0 + i of the column numbering
     {   // patch tables (see ddmp_graph): skipped when the rows of a chunk fan out too far (unordered numbering)
         const int64_t n_chunks = (n_rows + ddmp::kChunkRows - 1) / ddmp::kChunkRows;
         // by default from 64k rows for graphs with at most 12 entries per row ON AVERAGE (mesh graphs: 4 and ~7; the LDS
@@ -233,6 +234,26 @@ extern "C" int ddmp_graph_create_csr_host(int64_t n_rows, int64_t n_cols, const 
     for (int64_t e = 0; e < rowptr[n_rows]; ++e)
         if (col[e] < 0 || col[e] >= n_cols) return DDMP_ERANGE;
     return upload_graph(n_rows, n_cols, rowptr, col, dinv, out);
+}
+
+// Rows [row0, row1) of a local CSR as a graph of their own (round 6: the interior / boundary halves of a partitioned graph,
+// so that the halo exchange of a layer travels while the interior rows are aggregated -- dual-dmp_amd/dist.py): output row i
+// is node row0 + i, the columns keep the numbering of the whole local graph (X is the same tensor, Y starts at row row0).
+extern "C" int ddmp_graph_create_csr_rows_host(int64_t n_rows_all, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                                               const float* dinv, int64_t row0, int64_t row1, ddmp_graph** out) {
+    ARG_TRY(out && n_rows_all > 0 && n_cols >= n_rows_all && rowptr && col && dinv && row0 >= 0 && row1 > row0 && row1 <= n_rows_all);
+    ARG_TRY(rowptr[0] == 0);
+    for (int64_t i = 0; i < n_rows_all; ++i) ARG_TRY(rowptr[i + 1] >= rowptr[i]);
+    for (int64_t e = rowptr[row0]; e < rowptr[row1]; ++e)
+        if (col[e] < 0 || col[e] >= n_cols) return DDMP_ERANGE;
+    std::vector<int32_t> rp;
+    try {
+        rp.resize((size_t)(row1 - row0) + 1);
+    } catch (const std::bad_alloc&) {
+        return DDMP_ENOMEM;
+    }
+    for (int64_t i = row0; i <= row1; ++i) rp[(size_t)(i - row0)] = rowptr[i] - rowptr[row0];
+    return upload_graph(row1 - row0, n_cols, rp.data(), col + rowptr[row0], dinv, out, row0);
 }
 
 extern "C" int ddmp_graph_create(int64_t n, int64_t nnz, const int64_t* edge_index, int on_device,

@@ -27,7 +27,7 @@ constexpr int kMaxE = kRB * 16;    // staged CSR entries per chunk (mesh graphs:
 
 template <int LANES, int CHUNKS, bool PRO>
 __global__ __launch_bounds__(256) void spmm_vec_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv, const float* __restrict__ dinv_r,
     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope, int chunks_per_xcd, int n_chunks) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(
                 }
             }
         }
-        const float di = dinv[row];
+        const float di = dinv_r[row];
         float* yr = Y + (int64_t)row * ldy + sl * 4;
 #pragma unroll
         for (int c = 0; c < CHUNKS; ++c) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(
 // any width: one thread per (row, channel)
 template <bool PRO>
 __global__ __launch_bounds__(256) void spmm_scalar_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv, const float* __restrict__ dinv_r,
     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void spmm_scalar_kernel(
             if (PRO) t = lrelu(fmaf(t, pscale[c], pshift[c]), slope);
             acc = fmaf(dinv[j], t, acc);
         }
-        Y[(int64_t)row * ldy + c] = fmaf(acc, dinv[row], bias ? bias[c] : 0.f);
+        Y[(int64_t)row * ldy + c] = fmaf(acc, dinv_r[row], bias ? bias[c] : 0.f);
     }
 }
 
@@ -186,7 +186,7 @@ struct BnBwdGather {
 
 template <int LANES, int U, int NR, bool PRO, int SL, bool RED = false, bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_slab_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv, const float* __restrict__ dinv_r,
     const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope, int chunks_per_xcd, int n_chunks, BnRed red = BnRed(), BnBwdGather bwd = BnBwdGather()) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void spmm_slab_kernel(
                 const int lr = lr0 + q * RPB;
                 if (lr < nr) {
                     const int row = r0 + lr;
-                    const float di = dinv[row];
+                    const float di = dinv_r[row];
 #pragma unroll
                     for (int s = 0; s < SL; ++s) {
                         float4 o;
@@ -374,7 +374,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         const int want = std::min(n_sl, std::max(1, 2048 / n_list));
         const int per = (n_sl + want - 1) / want;
         const int groups_l = (n_sl + per - 1) / per;
-        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list, groups_l), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X,
+        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list, groups_l), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
         LAUNCH_TRY();
         return DDMP_OK;
@@ -390,7 +390,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         const int per = (n_slabs + want - 1) / want;
         groups = (n_slabs + per - 1) / per;
     }
-    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, X, ldx,
+    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X, ldx,
                        Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, (const int*)nullptr, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -409,10 +409,10 @@ int launch_slab(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int6
         if (lp.kind) return launch_lean<false, 0, false>(lp, g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st);
     }
     if (ps)
-        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
+        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, true, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
     else
-        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, false, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, X,
+        hipLaunchKernelGGL((spmm_slab_kernel<LANES, U, NR, false, SL>), grid, block, 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -427,10 +427,10 @@ int launch_vec(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64
     dim3 grid(cpx * kXcd), block(256);
     if (ps)
         hipLaunchKernelGGL((spmm_vec_kernel<LANES, CHUNKS, true>), grid, block, 0, st, g->rowptr, g->col,
-                           g->dinv, X, ldx, Y, ldy, n, bias, ps, psh, slope, cpx, n_chunks);
+                           g->dinv, g->dinv_r, X, ldx, Y, ldy, n, bias, ps, psh, slope, cpx, n_chunks);
     else
         hipLaunchKernelGGL((spmm_vec_kernel<LANES, CHUNKS, false>), grid, block, 0, st, g->rowptr, g->col,
-                           g->dinv, X, ldx, Y, ldy, n, bias, ps, psh, slope, cpx, n_chunks);
+                           g->dinv, g->dinv_r, X, ldx, Y, ldy, n, bias, ps, psh, slope, cpx, n_chunks);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -497,10 +497,10 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
     const int64_t total = g->n_rows * (int64_t)C;
     const int grid = (int)std::min<int64_t>(cdiv(total, 256), 256 * 16);
     if (pro_scale)
-        hipLaunchKernelGGL((spmm_scalar_kernel<true>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->dinv,
+        hipLaunchKernelGGL((spmm_scalar_kernel<true>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r,
                            X, ldx, Y, ldy, (int)g->n_rows, C, bias, pro_scale, pro_shift, slope);
     else
-        hipLaunchKernelGGL((spmm_scalar_kernel<false>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->dinv,
+        hipLaunchKernelGGL((spmm_scalar_kernel<false>), dim3(grid), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r,
                            X, ldx, Y, ldy, (int)g->n_rows, C, bias, pro_scale, pro_shift, slope);
     LAUNCH_TRY();
     return DDMP_OK;
@@ -559,7 +559,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
         red_groups = lp.n_chunks;                                // lean kernel: one record per chunk
     } else {
         hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, false, 1, true>), dim3(cpx * kXcd), dim3(256), 0, st, g->rowptr, g->col,
-                           g->dinv, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           g->dinv, g->dinv_r, X, ldx, Y, ldy, n, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            slope, cpx, n_chunks, red);
         LAUNCH_TRY();
     }
@@ -628,7 +628,7 @@ extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t
     const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, ld_out, C, 4) : LeanPlan{0, 0};   // one staged offset serves both matrices
     if (lp.kind) return launch_lean<true, 0, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
-                       (hipStream_t)stream, g->rowptr, g->col, g->dinv, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,
+                       (hipStream_t)stream, g->rowptr, g->col, g->dinv, g->dinv_r, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,
                        a, b, slope, cpx, n_chunks, BnRed(), bwd);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -74,7 +74,7 @@ template <int VW> __device__ __forceinline__ void ldcf(const float* p, float (&f
 // slots exceed the LDS array reads its entries from global memory), `chunk_list` = the LDS-patch kernel's heavy chunks.
 template <int VW, int LANES, int U, bool PRO, int RED, bool BWD, bool LEAN>
 __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv,
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dinv, const float* __restrict__ dinv_r,
     const bf16_t* __restrict__ X, int64_t ldx, bf16_t* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift,
     float slope, int chunks_per_xcd, int n_chunks, const int* __restrict__ chunk_list, BnRedB red, BnBwdGatherB bwd) {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void spmm_slab_b16_kernel(
                 es += U;
             }
             const int row = r0 + lr;
-            const float di = dinv[row];
+            const float di = dinv_r[row];
             float o[VW], bs[VW];
 #pragma unroll
             for (int j = 0; j < VW; ++j) bs[j] = 0.f;
@@ -376,10 +376,10 @@ int launch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int
     const bool lean = lean_on && lean_b16_ok(g, ldx) && (!BWD || bwd.ldyb == ldx);
     if (lean)
         hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, true>), grid, dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
+                           g->col, g->dinv, g->dinv_r, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     else
         hipLaunchKernelGGL((spmm_slab_b16_kernel<VW, LANES, 4, PRO, RED, BWD, false>), grid, dim3(256), 0, st, g->rowptr,
-                           g->col, g->dinv, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
+                           g->col, g->dinv, g->dinv_r, X, ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, heavy, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -77,7 +77,7 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 template <typename T, int KD, bool PRO, int RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-    const float* __restrict__ dinv, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
+    const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
     const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
     int chunks_per_xcd, int n_chunks, RedArgs red) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int grp = lane >> 3, sl = lane & 7;
 
     for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
-    for (int i = tid; i < nr; i += 256) s_dinv[i] = dinv[r0 + i];
+    for (int i = tid; i < nr; i += 256) s_dinv[i] = dinv_r[r0 + i];
     const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
     if (np <= 0) return;                                         // a heavy chunk: the lean gather's (uniform: before any barrier)
     for (int i = tid; i < PR; i += 256) s_pl[i] = pl_col[p0 + min(i, np - 1)];      // padded with the last row
@@ -408,7 +408,7 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
         }
         attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->pl_ptr, g->pl_col, X,
+    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, X,
                        ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -771,14 +771,15 @@ class DistributedTrainer:
                           "eagerly (set DDMP_DIST_GRAPH_PEERS=1 to capture anyway)" % backend.world_size)
             self.use_graph = False
         if self.use_graph:
-            # ONE communicator under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1 (tests/test_gpu_multi.py): the
-            # captured iteration replays correctly with one communicator; with a SECOND communicator in the same capture it ends
-            # in a SIGSEGV (two streams) or never returns (one stream).  Round 6: the stream is forked INSIDE the capture and both
-            # nets use the one communicator (RCCL serialises a communicator's operations in issue order, which is the same on
-            # every rank: PosNet's forward, NormalNet's forward, ...) -- DDMP_DIST_GRAPH_STREAMS=1 keeps the single stream.
-            # With peers the two-stream form is opt-in (DDMP_DIST_GRAPH_STREAMS=2): like the capture itself it has only run on
-            # a one-rank loopback communicator.
-            want2 = os.environ.get("DDMP_DIST_GRAPH_STREAMS", "2" if backend.world_size == 1 else "1") == "2"
+            # ONE communicator on ONE stream under capture.  Measured on ROCm 7.2 with DDMP_COMM_LOOPBACK=1 (tests/test_gpu_multi.py,
+            # profiles/r06_dist_overhead.txt): the captured iteration replays correctly with one communicator on one stream; a
+            # second communicator in the same capture ends in a SIGSEGV (two streams) or never returns (one stream), and -- round
+            # 6 -- so does ONE communicator whose operations are captured on two forked streams (SIGSEGV inside the capture): RCCL
+            # operations cannot be captured on a forked stream here.  Two streams under capture are therefore taken only where
+            # no RCCL call is issued at all (one rank without DDMP_COMM_LOOPBACK: 8.02 instead of 8.30 ms at 125k faces);
+            # DDMP_DIST_GRAPH_STREAMS=1|2 overrides.
+            quiet = backend.world_size == 1 and os.environ.get("DDMP_COMM_LOOPBACK") != "1"
+            want2 = os.environ.get("DDMP_DIST_GRAPH_STREAMS", "2" if quiet else "1") == "2"
             backend_pos = backend if want2 else None
         with ctx:
             self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,

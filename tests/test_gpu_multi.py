@@ -24,7 +24,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     ("grid", "sharded", "0", "1", "0", {"DDMP_COMM_LOOPBACK": "1"}),
     ("grid", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1"}),
     ("grid", "sharded", "0", "1", "0", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"}),
-    ("ico4", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"})])
+    ("ico4", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"}),
+    # round 6: one rank WITHOUT the loopback issues no RCCL call: there the capture forks PosNet's stream (RCCL operations on a
+    # forked stream end the capture in a SIGSEGV on ROCm 7.2, with one communicator as with two: profiles/r06_dist_overhead.txt)
+    ("grid", "sharded", "0", "1", "1", {"DDMP_DIST_GRAPH": "1"})])
 def test_rccl_ranks_match_single_device(kind, losses, interleave, native, streams, extra):
     n = min(2, torch.cuda.device_count())                   # counting devices does not initialise the GPU in this process
     assert n >= 1
@@ -39,5 +42,5 @@ def test_rccl_ranks_match_single_device(kind, losses, interleave, native, stream
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "PARITY" in r.stdout, tail
     if extra.get("DDMP_DIST_GRAPH"):
-        # round 6: with DDMP_DIST_STREAMS=1 the capture forks PosNet's stream INSIDE the graph, both nets on the ONE communicator
-        assert "captured=1" in r.stdout and ("streams=%d" % (2 if streams == "1" else 1)) in r.stdout, tail
+        two = streams == "1" and "DDMP_COMM_LOOPBACK" not in extra
+        assert "captured=1" in r.stdout and ("streams=%d" % (2 if two else 1)) in r.stdout, tail
