@@ -104,6 +104,39 @@ def vertex_owner_from_faces(faces: np.ndarray, face_owner: np.ndarray, n_verts: 
     return owner
 
 
+CHUNK = 64                                                       # rows per gather chunk (csrc: ddmp::kChunkRows)
+
+
+def interior_first_keys(rowptr: np.ndarray, col: np.ndarray, owner: np.ndarray, key: np.ndarray, P: int) -> np.ndarray:
+    """Per owner, a new local order of its rows: the 64-row chunks of the order `key` are kept as they are (a chunk is a compact
+    patch of the surface: gather locality), but the chunks in which no row has a neighbour on another rank come FIRST -- the
+    rows a rank can aggregate before its halo rows have arrived (the halo exchange is overlapped with them).  A
+    ragged last chunk stays last.  Returns the new key (only its order within an owner matters)."""
+    n = len(rowptr) - 1
+    owner = owner.astype(np.int64)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr).astype(np.int64))
+    touches = np.zeros(n, dtype=bool)
+    touches[rows[owner[rows] != owner[col.astype(np.int64)]]] = True
+    order = np.lexsort((key, owner))
+    off = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=P))])
+    new = np.empty(n, dtype=np.int64)
+    for r in range(P):
+        ids = order[off[r]:off[r + 1]]
+        m = len(ids)
+        if m == 0:
+            continue
+        ch = np.arange(m) // CHUNK
+        nch = int(ch[-1]) + 1
+        bnd = np.zeros(nch, dtype=bool)
+        np.logical_or.at(bnd, ch, touches[ids])
+        if m % CHUNK:
+            bnd[-1] = True
+        pos = np.empty(nch, dtype=np.int64)
+        pos[np.argsort(bnd, kind="stable")] = np.arange(nch)
+        new[ids] = pos[ch] * CHUNK + np.arange(m) % CHUNK
+    return new
+
+
 class HaloPlan:
     """Everything rank `rank` needs for one graph: local CSR over [owned | halo], global ids, and the
     all-to-all schedule.  Built identically (deterministically) on every rank from the global CSR."""
@@ -150,6 +183,16 @@ class HaloPlan:
         self.local_ids = np.concatenate([self.owned, self.halo])
         self.dinv = dinv[self.local_ids].astype(np.float32)
         self.n_global = n
+        # rows [0, n_int): the leading 64-row chunks none of whose rows references a halo row -- what can be aggregated while the
+        # halo rows are still travelling (interior_first_keys puts every such chunk in front)
+        touches = np.zeros(n, dtype=bool)
+        touches[rows[cut]] = True
+        nch = (self.n_rows + CHUNK - 1) // CHUNK
+        flags = np.zeros(max(nch, 1), dtype=bool)
+        if self.n_rows:
+            np.logical_or.at(flags, np.arange(self.n_rows) // CHUNK, touches[self.owned])
+        lead = int(np.argmax(flags)) if flags.any() else nch
+        self.n_int = int(min(lead * CHUNK, self.n_rows))
 
 
 # ------------------------------------------------------------------------------------ communicators
@@ -197,6 +240,19 @@ class GraphComm:
             return None
         return start(recv, send, p.recv_counts, p.send_counts)
 
+    def start_halo_overlapped(self, t: torch.Tensor, n_rows: int):
+        """Start the exchange of `t`'s halo rows so that it runs BESIDE what the caller enqueues next (the aggregation of the
+        interior rows, which reference no halo row: GcnEngine split mode); the returned handle's wait() orders the caller's
+        stream behind it.  Native RCCL backend with an exchange stream (NativeComm.use_xs): pack + grouped send/recv go to the
+        communicator's exchange stream behind an event of the current stream (the producer of `t`); other backends: start_halo
+        (asynchronous where the backend can)."""
+        native = getattr(self.backend, "halo_exchange_native", None)
+        if native is None or not getattr(self.backend, "use_xs", False) or torch.cuda.is_current_stream_capturing():
+            return self.start_halo(t, n_rows)
+        p = self.plan
+        assert t.shape[0] >= p.n_cols and n_rows == p.n_rows and t.is_contiguous()
+        return native(p, t, defer=True)
+
     def halo_and_sums(self, t: torch.Tensor, n_rows: int, sums: torch.Tensor) -> bool:
         """The halo rows of `t` and the all-reduce of the BatchNorm column sums in ONE grouped RCCL launch (native
         backend only; False = not available, the caller issues the two collectives separately)."""
@@ -212,6 +268,16 @@ class GraphComm:
             self.backend.all_reduce_sum(t)
             return None
         return start(t)
+
+
+class _StreamWait:
+    """An exchange enqueued on another stream: wait() orders the CURRENT stream behind it (no host wait)."""
+
+    def __init__(self, done):
+        self.done = done
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
 
 
 class _Pending:
@@ -305,6 +371,30 @@ class NativeComm:
             _lib.check(self.L.ddmp_comm_create(self.rank, self.world_size, ctypes.c_char_p(box[0]), ctypes.byref(h)), "ddmp_comm_create")
         self.h = h
         self._plans = {}
+        # Exchange stream (round 6, DistributedTrainer(overlap_halo=True)): EVERY RCCL call of this communicator is enqueued on
+        # one stream of its own, behind an event of the caller's stream, and the caller's stream waits for its completion event
+        # -- at once (all-reduces, all-gathers, blocking exchanges) or, for start_halo_overlapped, when the boundary rows are
+        # about to be aggregated.  One communicator <-> one stream, whatever stream the kernels run on; never under capture.
+        self.use_xs = False
+        self.xs = None
+
+    def _on_xs(self, fn, defer=False):
+        if not self.use_xs or torch.cuda.is_current_stream_capturing():
+            fn()
+            return None
+        if self.xs is None:
+            self.xs = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        self.xs.wait_event(ready)
+        with torch.cuda.stream(self.xs):
+            fn()
+            done = torch.cuda.Event()
+            done.record(self.xs)
+        if defer:
+            return _StreamWait(done)
+        torch.cuda.current_stream().wait_event(done)
+        return None
 
     def plan_handle(self, plan: "HaloPlan"):
         key = id(plan)
@@ -320,24 +410,28 @@ class NativeComm:
             self._plans[key] = (h, plan)
         return self._plans[key][0]
 
-    def halo_exchange_native(self, plan, t, sums=None):
+    def halo_exchange_native(self, plan, t, sums=None, defer=False):
+        """``defer``: return a handle whose wait() orders the caller's stream behind the exchange (exchange stream only)."""
         h = self.plan_handle(plan)
         dt = ops._dt(t)
-        ws = ops.Workspace.get(self.L.ddmp_halo_pack_bytes(h, t.shape[1], dt), t.device)
-        _lib_check(self.L.ddmp_halo_exchange(self.h, h, ops._p(t), t.stride(0), t.shape[1], dt, ops._p(ws), ws.numel(),
-                                             ops._p(sums), 0 if sums is None else sums.numel(), ops._stream()), "ddmp_halo_exchange")
-        return t
+
+        def go():
+            ws = ops.Workspace.get(self.L.ddmp_halo_pack_bytes(h, t.shape[1], dt), t.device)     # (per stream: the exchange stream's own)
+            _lib_check(self.L.ddmp_halo_exchange(self.h, h, ops._p(t), t.stride(0), t.shape[1], dt, ops._p(ws), ws.numel(),
+                                                 ops._p(sums), 0 if sums is None else sums.numel(), ops._stream()), "ddmp_halo_exchange")
+        w = self._on_xs(go, defer)
+        return w if defer else t
 
     def all_reduce_sum(self, t):
         assert t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
-        _lib_check(self.L.ddmp_comm_allreduce_sum(self.h, ops._p(t), t.numel(), 1 if t.dtype == torch.float64 else 0, ops._stream()),
-                   "ddmp_comm_allreduce_sum")
+        self._on_xs(lambda: _lib_check(self.L.ddmp_comm_allreduce_sum(self.h, ops._p(t), t.numel(), 1 if t.dtype == torch.float64 else 0,
+                                                                      ops._stream()), "ddmp_comm_allreduce_sum"))
         return t
 
     def all_gather_rows(self, out, local):
         local = local.contiguous()
-        _lib_check(self.L.ddmp_comm_allgather(self.h, ops._p(local), ops._p(out), local.numel() * local.element_size(), ops._stream()),
-                   "ddmp_comm_allgather")
+        self._on_xs(lambda: _lib_check(self.L.ddmp_comm_allgather(self.h, ops._p(local), ops._p(out), local.numel() * local.element_size(),
+                                                                  ops._stream()), "ddmp_comm_allgather"))
         return out
 
     def barrier(self):
@@ -544,6 +638,10 @@ def _shared_global_tables(dataset, n_mesh, P, face_owner):
         vkey[rcb_order(dataset.x_pos.detach().cpu().double().numpy(), 64)] = np.arange(V)
         fkey = np.empty(F, dtype=np.int64)
         fkey[rcb_order(np.asarray(n_mesh.fc, dtype=np.float64), 64)] = np.arange(F)
+        vcsr, fcsr = global_csr(ei, V), global_csr(fi, F)
+        if P > 1:                                                # chunks without a remote neighbour first (round 6)
+            vkey = interior_first_keys(vcsr[0], vcsr[1], vert_owner, vkey, P)
+            fkey = interior_first_keys(fcsr[0], fcsr[1], face_owner, fkey, P)
         # where every rank's owned rows (in its local order: increasing Morton key) go in the global arrays: the
         # replicated losses are fed by ONE all-gather of the owned pos | norm rows, padded to the largest shard
         vord, ford = np.lexsort((vkey, vert_owner)), np.lexsort((fkey, face_owner))
@@ -555,7 +653,7 @@ def _shared_global_tables(dataset, n_mesh, P, face_owner):
         for r in range(P):
             gather_dst[r, :vcnt[r]] = vord[vo[r]:vo[r + 1]]
             gather_dst[r, vcnt[r]:vcnt[r] + fcnt[r]] = V + ford[fo[r]:fo[r + 1]]
-        tables = dict(face_owner=face_owner, vert_owner=vert_owner, vcsr=global_csr(ei, V), fcsr=global_csr(fi, F),
+        tables = dict(face_owner=face_owner, vert_owner=vert_owner, vcsr=vcsr, fcsr=fcsr,
                       vkey=vkey, fkey=fkey, gather_dst=gather_dst.reshape(-1), gather_rows=m)
         if len(_global_tables) > 4:
             _global_tables.clear()
@@ -737,8 +835,14 @@ class DistributedTrainer:
 
     def __init__(self, posnet, normnet, sharded: ShardedData, n_mesh, backend, device, pos_lr=0.01, norm_lr=0.01,
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
-                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None, use_graph=None):
-        """``use_graph`` (default: env DDMP_DIST_GRAPH=1; it OVERRIDES DDMP_DIST_STREAMS: a captured iteration uses one
+                 bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None, use_graph=None,
+                 overlap_halo=None):
+        """``overlap_halo`` (default: on with more than one rank, env DDMP_DIST_SPLIT=0 switches it off, =1 forces it at one rank
+        too): every aggregation runs as two launches -- the rows that reference no halo row (HaloPlan.n_int: the leading chunks of
+        the interior-first local order) while the layer's halo exchange travels on the communicator's exchange stream, the
+        boundary rows behind it (engine.GcnEngine ``split``).  Eager path only: a captured iteration keeps whole-graph launches.
+
+        ``use_graph`` (default: env DDMP_DIST_GRAPH=1; it OVERRIDES DDMP_DIST_STREAMS: a captured iteration uses one
         communicator on one stream; with more than one rank it is refused unless DDMP_DIST_GRAPH_PEERS=1, see below): replay the
         partitioned iteration as ONE hipGraph -- every kernel and,
         with the native RCCL backend, every collective is enqueued on the capturing stream(s) from C (csrc/comm.hip); the Adam
@@ -781,6 +885,10 @@ class DistributedTrainer:
             quiet = backend.world_size == 1 and os.environ.get("DDMP_COMM_LOOPBACK") != "1"
             want2 = os.environ.get("DDMP_DIST_GRAPH_STREAMS", "2" if quiet else "1") == "2"
             backend_pos = backend if want2 else None
+        if overlap_halo is None:
+            e = os.environ.get("DDMP_DIST_SPLIT")
+            overlap_halo = (backend.world_size > 1) if e is None else e != "0"
+        self.overlap_halo = bool(overlap_halo) and not self.use_graph
         with ctx:
             self._init(posnet, normnet, sharded, n_mesh, backend, device, pos_lr, norm_lr, k, grad_crip, bnfloop, betas,
                        eps, bnf_start_epoch, ops_mod, loss_engine, losses, backend_pos)
@@ -806,12 +914,23 @@ class DistributedTrainer:
                             and os.environ.get("DDMP_DIST_STREAMS", "1") != "0")
         self.backend_pos = backend_pos if self.two_streams else backend
         self._side = torch.cuda.Stream(device=device) if self.two_streams else None
+        def halves(plan):
+            """The interior / boundary halves of a rank's graph (None: nothing to split -- no interior chunk, or no boundary)."""
+            if not getattr(self, "overlap_halo", False) or not 0 < plan.n_int < plan.n_rows:
+                return None
+            mk = self.ops.Graph.from_csr_host
+            return (mk(plan.rowptr, plan.col, plan.dinv, plan.n_cols, rows=(0, plan.n_int)),
+                    mk(plan.rowptr, plan.col, plan.dinv, plan.n_cols, rows=(plan.n_int, plan.n_rows)), plan.n_int)
+        if getattr(self, "overlap_halo", False):
+            for b in {id(backend): backend, id(self.backend_pos): self.backend_pos}.values():
+                if hasattr(b, "use_xs") and torch.device(device).type == "cuda":
+                    b.use_xs = True                              # every RCCL call of the communicator on its exchange stream
         self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
                               comm=GraphComm(self.backend_pos, sd.vplan, device), n_total=sd.V,
-                              dtype=getattr(posnet, "feature_dtype", torch.float32))
+                              dtype=getattr(posnet, "feature_dtype", torch.float32), split=halves(sd.vplan))
         self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
                               comm=GraphComm(backend, sd.fplan, device), n_total=sd.F,
-                              dtype=getattr(normnet, "feature_dtype", torch.float32))
+                              dtype=getattr(normnet, "feature_dtype", torch.float32), split=halves(sd.fplan))
         for net, eng in ((posnet, self.peng), (normnet, self.neng)):
             if hasattr(net, "attach_engine"):
                 net.attach_engine(eng)                          # net(data) then runs on this rank's shard

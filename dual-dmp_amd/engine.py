@@ -168,7 +168,7 @@ class GcnEngine:
 
     def __init__(self, graph: ops.Graph, widths: List[int], kind: int, x0: torch.Tensor,
                  x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None,
-                 perm: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32):
+                 perm: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32, split=None):
         """``perm`` (int64 [n_rows], new -> old): the engine works on nodes relabelled for gather locality
         (``graph`` and ``x0``/``x_pos`` must already be in the NEW numbering); :meth:`forward` returns and
         :meth:`backward` accepts rows in the caller's ORIGINAL numbering.
@@ -181,6 +181,16 @@ class GcnEngine:
             raise ValueError("feature dtype must be torch.float32 or torch.bfloat16")
         self.dtype = dtype
         self.g = graph
+        # ``split`` = (g_int, g_bnd, n_int) (multi-device, round 6): the graph's rows [0, n_int) -- the leading 64-row chunks that
+        # reference no halo row -- and [n_int, n_rows) as graphs of their own (ops.Graph.from_csr_host(rows=...)).  Every
+        # aggregation then runs as two launches: the halo exchange of the gathered tensor is STARTED (comm.start_halo_overlapped),
+        # the interior rows are aggregated while it travels, the boundary rows behind it; fused column sums of the two halves are
+        # added in float64.  The same two launches with the exchange waited for first (DDMP_DIST_OVERLAP=0) give the same bits.
+        self.split = None
+        if split is not None and comm is not None and 0 < split[2] < graph.n_rows:
+            self.split = tuple(split)
+            self.n_int = int(split[2])
+        self._halo_ahead = None
         self.kind = kind
         self.layout = ArenaLayout(widths)
         self.comm = comm or NoComm()
@@ -261,6 +271,7 @@ class GcnEngine:
         self._f16 = False
         self._side = None
         self.sums = torch.empty(2 * cmax, dtype=torch.float64, device=dev)
+        self.sums_b = torch.empty(2 * cmax, dtype=torch.float64, device=dev) if self.split else None   # boundary half's sums
         self.running = [torch.zeros((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         for r in self.running:
             r[1].fill_(1.0)                                            # running_var starts at 1
@@ -366,6 +377,25 @@ class GcnEngine:
         """Keyword for the GEMM call of layer l (form 0 forward, 1 dgrad): its prepared planes, if any."""
         return {} if self._wplanes is None else {"wplanes": self._wplanes[(l, form)]}
 
+    # ------------------------------------------------------------------ split aggregation (see __init__: ``split``)
+    def _start_halo(self, t):
+        """Split mode: the exchange of t's halo rows, started beside the interior rows' aggregation (a handle to wait on)."""
+        comm, n = self.comm, self.n_rows
+        start = getattr(comm, "start_halo_overlapped", None)
+        if start is None or os.environ.get("DDMP_DIST_OVERLAP", "1") == "0":
+            h = comm.start_halo(t, n)                            # (A/B and bit-identity check: same launches, no overlap)
+            if h is not None:
+                h.wait()
+            return None
+        return start(t, n)
+
+    def _halves(self):
+        g_int, g_bnd, ni = self.split
+        return ((g_int, 0, ni, self.sums), (g_bnd, ni, self.n_rows, self.sums_b))
+
+    def _add_sums(self, width):
+        self.sums[:width] += self.sums_b[:width]
+
     def forward_steps(self, params: torch.Tensor, update_running: bool = True, use_running: bool = False):
         """The forward pass as a generator that yields at every collective it STARTS (halo exchange, BatchNorm
         statistics all-reduce): the caller waits on the handle before resuming.  A multi-device trainer runs the
@@ -390,7 +420,14 @@ class GcnEngine:
                                    running=(self.running[l][0], self.running[l][1]) if update_running else None)} if tail else {}
             if self.agg_first[l]:
                 P = self.P[l]
-                if l > 0 or not self._p1_ready:
+                if self.split and l > 0:
+                    h = self._halo_ahead if halo_started else self._start_halo(X)
+                    self._halo_ahead = None
+                    for k, (gh, r0, r1, _) in enumerate(self._halves()):
+                        if k == 1:
+                            yield h
+                        ops.spmm(gh, X, out=P[r0:r1], pro=pro)
+                elif l > 0 or not self._p1_ready:
                     if l > 0 and not halo_started:
                         yield comm.start_halo(X, n)
                     ops.spmm(g, X, out=P[:n], pro=pro)
@@ -403,17 +440,37 @@ class GcnEngine:
             else:
                 H = self._work(0, L.cout[l])
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0), **self._scales(l, 0))
-                yield comm.start_halo(H, n)
-                if self.fuse_spmm_stats[l]:
-                    ops.spmm_stats(g, H, Y[:n], self.bn4[l][2], self.sums, bias=b, **bnk)
+                if self.split:
+                    h = self._start_halo(H)
+                    for k, (gh, r0, r1, sums) in enumerate(self._halves()):
+                        if k == 1:
+                            yield h
+                        if self.fuse_spmm_stats[l]:
+                            ops.spmm_stats(gh, H, Y[r0:r1], self.bn4[l][2], sums, bias=b)
+                        else:
+                            ops.spmm(gh, H, out=Y[r0:r1], bias=b)
+                    if self.fuse_spmm_stats[l]:
+                        self._add_sums(2 * L.cout[l])
+                    else:
+                        ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
                 else:
-                    ops.spmm(g, H, out=Y[:n], bias=b)
-                    ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
+                    yield comm.start_halo(H, n)
+                    if self.fuse_spmm_stats[l]:
+                        ops.spmm_stats(g, H, Y[:n], self.bn4[l][2], self.sums, bias=b, **bnk)
+                    else:
+                        ops.spmm(g, H, out=Y[:n], bias=b)
+                        ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
             # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
             # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
             halo_started = l < 11 and self.agg_first[l + 1]
-            fused = getattr(comm, "halo_and_sums", None)
-            if halo_started and fused is not None and fused(Y, n, self.sums[: 2 * L.cout[l]]):
+            fused = None if self.split else getattr(comm, "halo_and_sums", None)
+            if self.split:
+                # the sums first (the next kernel's prologue needs them), the halo rows of Y behind them and beside the
+                # interior rows' aggregation of the next layer
+                yield comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
+                if halo_started:
+                    self._halo_ahead = self._start_halo(Y)
+            elif halo_started and fused is not None and fused(Y, n, self.sums[: 2 * L.cout[l]]):
                 yield None                                       # one grouped launch carried both (native RCCL backend)
             else:
                 h_stats = comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
@@ -516,6 +573,21 @@ class GcnEngine:
             ops.spmm(g, src, out=dst[:n])
             return False
 
+        def spmm_to_dz_split(src, dst, l):
+            """The same in split mode, as a generator: exchange started, interior rows, wait, boundary rows."""
+            h = self._start_halo(src)
+            red = fuse_red and l > 0
+            for k, (gh, r0, r1, sums) in enumerate(self._halves()):
+                if k == 1:
+                    yield h
+                if red:
+                    ops.spmm_bnred(gh, src, dst[r0:r1], self.Y[l - 1][r0:r1], self.bn4[l - 1], sums)
+                else:
+                    ops.spmm(gh, src, out=dst[r0:r1])
+            if red:
+                self._add_sums(2 * L.cout[l - 1])
+            return red
+
         # transform-first dgrads with the next BatchNorm-backward reductions in their epilogue (row-register kernel, float32).
         # Measured at 1M faces (interleaved A/B, 10 steps each): 47.49 / 47.35 ms with, 47.75 / 47.78 ms without.  (A first
         # version lost 0.9 ms: the 32 per-column coefficients of the epilogue were hoisted out of the tile loop as invariants and
@@ -556,9 +628,13 @@ class GcnEngine:
                 # the BatchNorm passes that follow
                 wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n, **self._scales(l, 1, 0)), kz)
                 release(kz)
-                yield comm.start_halo(dP, n)
-                kz, dZ = take(ci)
-                have_sums = spmm_to_dz(dP, dZ, l)
+                if self.split:
+                    kz, dZ = take(ci)
+                    have_sums = yield from spmm_to_dz_split(dP, dZ, l)
+                else:
+                    yield comm.start_halo(dP, n)
+                    kz, dZ = take(ci)
+                    have_sums = spmm_to_dz(dP, dZ, l)
                 release(kp)
                 continue
             if self.fuse_gather_bwd[l]:
@@ -590,16 +666,28 @@ class GcnEngine:
                 wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n, **self._scales(l, 1, 0)), ky)
                 if l > 0:
                     release(ky)
-                    yield comm.start_halo(dP, n)
-                    kz, dZ = take(ci)
-                    have_sums = spmm_to_dz(dP, dZ, l)
+                    if self.split:
+                        kz, dZ = take(ci)
+                        have_sums = yield from spmm_to_dz_split(dP, dZ, l)
+                    else:
+                        yield comm.start_halo(dP, n)
+                        kz, dZ = take(ci)
+                        have_sums = spmm_to_dz(dP, dZ, l)
                     release(kp)
                 else:
                     release(ky)
             else:
-                yield comm.start_halo(dY, n)
-                kh, dH = take(co)
-                ops.spmm(g, dY, out=dH[:n])
+                if self.split:
+                    h = self._start_halo(dY)
+                    kh, dH = take(co)
+                    for k, (gh, r0, r1, _) in enumerate(self._halves()):
+                        if k == 1:
+                            yield h
+                        ops.spmm(gh, dY, out=dH[r0:r1])
+                else:
+                    yield comm.start_halo(dY, n)
+                    kh, dH = take(co)
+                    ops.spmm(g, dY, out=dH[:n])
                 release(ky)
                 if l > 0:
                     kz, dZ = take(ci)

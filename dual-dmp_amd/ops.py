@@ -320,12 +320,21 @@ class Graph:
         return cls(h, int(num_nodes), int(num_nodes), int(ei.shape[1]) + int(num_nodes))
 
     @classmethod
-    def from_csr_host(cls, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, n_cols: int) -> "Graph":
+    def from_csr_host(cls, rowptr: np.ndarray, col: np.ndarray, dinv: np.ndarray, n_cols: int, rows=None) -> "Graph":
+        """``rows`` = (row0, row1): only these rows of the tables, as a graph of their own -- output row i is node row0 + i, the
+        columns keep the numbering of the whole local graph (same X, the output tensor starts at row row0): the interior /
+        boundary halves of a partitioned graph (dist.py)."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         col = np.ascontiguousarray(col, dtype=np.int32)
         dinv = np.ascontiguousarray(dinv, dtype=np.float32)
         n_rows = len(rowptr) - 1
         h = ctypes.c_void_p()
+        if rows is not None:
+            r0, r1 = int(rows[0]), int(rows[1])
+            st = _lib.lib().ddmp_graph_create_csr_rows_host(n_rows, int(n_cols), rowptr.ctypes.data, col.ctypes.data,
+                                                            dinv.ctypes.data, r0, r1, ctypes.byref(h))
+            check(st, "ddmp_graph_create_csr_rows_host")
+            return cls(h, r1 - r0, int(n_cols), int(rowptr[r1] - rowptr[r0]))
         st = _lib.lib().ddmp_graph_create_csr_host(n_rows, int(n_cols), rowptr.ctypes.data, col.ctypes.data,
                                                    dinv.ctypes.data, ctypes.byref(h))
         check(st, "ddmp_graph_create_csr_host")

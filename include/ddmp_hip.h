@@ -70,6 +70,11 @@ int ddmp_graph_create(int64_t n_nodes, int64_t nnz, const int64_t* edge_index, i
 /* from ready CSR tables on the host (partitioned graphs: n_rows owned rows, cols < n_cols) */
 int ddmp_graph_create_csr_host(int64_t n_rows, int64_t n_cols, const int32_t* rowptr_host,
                                const int32_t* col_host, const float* dinv_host, ddmp_graph** out);
+/* rows [row0, row1) of such tables as a graph of their own: output row i is node row0 + i, the columns keep the numbering of the
+ * whole local graph (pass the same X, and Y + row0 * ldy).  The interior / boundary halves of a partitioned graph (SURVEY.md 8e:
+ * the halo exchange of a layer travels while the rows that reference no halo row are aggregated -- dual-dmp_amd/dist.py) */
+int ddmp_graph_create_csr_rows_host(int64_t n_rows_all, int64_t n_cols, const int32_t* rowptr_host, const int32_t* col_host,
+                                    const float* dinv_host, int64_t row0, int64_t row1, ddmp_graph** out);
 int ddmp_graph_destroy(ddmp_graph* g);
 int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int* max_row_nnz);
 int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t** col, const float** dinv);

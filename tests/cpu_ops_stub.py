@@ -24,17 +24,21 @@ def _f(x, pro, slope):
 
 
 class Graph:
-    def __init__(self, rowptr, col, dinv, n_cols):
+    def __init__(self, rowptr, col, dinv, n_cols, row0=0):
         self.n_rows, self.n_cols, self.nnz = len(rowptr) - 1, int(n_cols), int(rowptr[-1])
         rows = np.repeat(np.arange(self.n_rows), np.diff(rowptr))
         d = torch.from_numpy(np.asarray(dinv, dtype=np.float64))
-        vals = d[torch.from_numpy(rows)] * d[torch.from_numpy(np.asarray(col, dtype=np.int64))]
+        vals = d[torch.from_numpy(rows + row0)] * d[torch.from_numpy(np.asarray(col, dtype=np.int64))]
         idx = torch.from_numpy(np.stack([rows, np.asarray(col, dtype=np.int64)]))
         self.A = torch.sparse_coo_tensor(idx, vals, size=(self.n_rows, self.n_cols)).coalesce()
 
     @classmethod
-    def from_csr_host(cls, rowptr, col, dinv, n_cols):
-        return cls(np.asarray(rowptr), np.asarray(col), np.asarray(dinv), n_cols)
+    def from_csr_host(cls, rowptr, col, dinv, n_cols, rows=None):
+        rowptr, col = np.asarray(rowptr), np.asarray(col)
+        if rows is not None:                                    # a row slice of the local graph (ops.Graph.from_csr_host)
+            r0, r1 = int(rows[0]), int(rows[1])
+            return cls(rowptr[r0:r1 + 1] - rowptr[r0], col[rowptr[r0]:rowptr[r1]], np.asarray(dinv), n_cols, row0=r0)
+        return cls(rowptr, col, np.asarray(dinv), n_cols)
 
     @classmethod
     def from_edge_index(cls, edge_index, n):

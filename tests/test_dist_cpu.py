@@ -110,7 +110,8 @@ def _rank_run(rank, P, backend, noisy, smooth, data, steps, stub, oracle, result
     for _ in range(steps):
         loss = float(tr.step())
         out.append((loss, tr.gather_pos().clone(), tr.gather_norm().clone()))
-    results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone())
+    results[rank] = (out, tr.posnet.arena.detach().clone(), tr.normnet.arena.detach().clone(),
+                     (tr.peng.split is not None, tr.neng.split is not None))
 
 
 def _compare(ref, got, ref_nets, tag):
@@ -164,6 +165,52 @@ def test_threaded_ranks_match_unpartitioned(monkeypatch, oracle, P, kind):
         bad += int((d > 1e-4).sum())
         tot += d.numel()
     assert bad <= 1e-3 * tot, (bad, tot)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_split_aggregation_matches_unsplit_and_unpartitioned(monkeypatch, oracle, P):
+    """Round 6: every aggregation as interior rows (the leading chunks of the interior-first local
+    order, which reference no halo row: aggregated while the exchange travels) + boundary rows.  On a mesh large enough to HAVE
+    interior chunks on every rank and both graphs (asserted): the split run == the unsplit run of the same partition to float64
+    rounding of the stub (column sums of the halves are added: another association), and == the unpartitioned run like every other
+    partitioned test."""
+    import cpu_ops_stub as stub
+    from dual_dmp_amd import dist as D, synth
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    _patch(monkeypatch.setattr, stub)
+    v, f = synth.torus(48, 24) if P == 2 else synth.torus(96, 48)        # 2304 faces / 1152 vertices; 9216 / 4608
+    v, f = synth.permute_vertices(v, f, 2)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+    ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
+    runs = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("DDMP_DIST_SPLIT", split)
+        comms = D.ThreadComm.make(P)
+        results, errs, nets = {}, [], []
+        for _ in range(P):
+            torch.manual_seed(0)
+            nets.append((PosNet("cpu"), NormalNet("cpu")))
+
+        def work(r):
+            try:
+                _rank_run(r, P, comms[r], noisy, smooth, data, 2, stub, oracle, results, nets=nets[r])
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                comms[r].s.barrier.abort()
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs
+        runs[split] = results
+        for r in range(P):
+            assert results[r][3] == ((True, True) if split == "1" else (False, False)), (split, r, results[r][3])
+            _compare(ref[0], results[r], ref, "split%s rank%d" % (split, r))
+    for r in range(P):
+        for (l1, p1, n1), (l0, p0, n0) in zip(runs["1"][r][0], runs["0"][r][0]):
+            assert abs(l1 - l0) <= 5e-7 * abs(l0)             # (float32 outputs of the stub: rounding of the added sums)
+            assert float((p1 - p0).abs().max()) < 5e-6 and float((n1 - n0).abs().max()) < 5e-6
 
 
 def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated"):

@@ -131,3 +131,64 @@ def test_sharded_losses_match_whole_mesh_losses(P, kind, loop, partition):
         if partition == "morton" and loop == 1:
             assert ls.vplan.n_cols < V and ls.fplan.n_cols < F                     # a closure, not the whole mesh
     assert bool(seen_v.all()) and bool(seen_f.all())
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_interior_boundary_split_is_bit_identical_with_and_without_overlap(P, monkeypatch):
+    """Round 6: with more than one rank every aggregation runs as two launches -- the rows that
+    reference no halo row (the leading chunks of the interior-first local order) while the layer's halo exchange travels, the
+    boundary rows behind it (GcnEngine ``split``; row-slice graphs of ddmp_graph_create_csr_rows_host).  48,400 faces over P
+    threaded ranks, gate open, bnfloop 2, two iterations:
+      * split + overlap (default) vs the same two launches with every exchange waited for first (DDMP_DIST_OVERLAP=0): bit-identical
+        losses, outputs and parameters;
+      * vs the unsplit partitioned path (DDMP_DIST_SPLIT=0: one launch per aggregation): equal to float32 rounding -- the fused
+        column sums of the two halves are added in float64, another association of the same terms;
+      * the split really happened on every rank and both graphs (asserted)."""
+    from dual_dmp_amd import synth, dist as D
+    from dual_dmp_amd.datamaker import dataset_from_meshes
+    from dual_dmp_amd.networks import PosNet, NormalNet
+    dev = torch.device("cuda:0")
+    v, f = synth.torus(220, 110)
+    v, f = synth.permute_vertices(v, f, 4)
+    gt, noisy, smooth = synth.make_triplet(v, f)
+    data = dataset_from_meshes(noisy, smooth)
+
+    def run(env):
+        for k in ("DDMP_DIST_SPLIT", "DDMP_DIST_OVERLAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        nets = []
+        for _ in range(P):
+            torch.manual_seed(0)
+            nets.append((PosNet(dev), NormalNet(dev)))
+        comms = D.ThreadComm.make(P)
+        results, errs = {}, []
+
+        def work(r):
+            try:
+                torch.cuda.set_device(0)
+                tr = D.make_distributed_trainer(noisy, smooth, data, dev, r, P, bnfloop=2, backend=comms[r], nets=nets[r])
+                tr.epoch = 100
+                hist = [(tr.step().item(), tr.gather_pos().clone(), tr.gather_norm().clone()) for _ in range(2)]
+                results[r] = (hist, tr.posnet.arena.data.clone(), tr.normnet.arena.data.clone(),
+                              (tr.peng.split is not None, tr.neng.split is not None), (tr.peng.n_int if tr.peng.split else 0, tr.peng.n_rows))
+            except BaseException as e:       # noqa: BLE001
+                errs.append(e)
+                comms[r].s.barrier.abort()
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs
+        return results
+
+    a, b, c = run({}), run({"DDMP_DIST_OVERLAP": "0"}), run({"DDMP_DIST_SPLIT": "0"})
+    for r in range(P):
+        assert a[r][3] == (True, True) and b[r][3] == (True, True) and c[r][3] == (False, False), (r, a[r][3], c[r][3])
+        assert 0 < a[r][4][0] < a[r][4][1]
+        for (la, pa, na), (lb, pb, nb), (lc, pc, nc) in zip(a[r][0], b[r][0], c[r][0]):
+            assert la == lb and torch.equal(pa, pb) and torch.equal(na, nb)
+            assert abs(la - lc) <= 2e-6 * abs(lc), (la, lc)
+        assert torch.equal(a[r][1], b[r][1]) and torch.equal(a[r][2], b[r][2])
+    (l1, p1, n1), (lc1, pc1, nc1) = a[0][0][0], c[0][0][0]
+    assert float((p1 - pc1).abs().max()) < 2e-5 and float((n1 - nc1).abs().max()) < 2e-5

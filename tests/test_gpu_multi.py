@@ -27,7 +27,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     ("ico4", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_GRAPH": "1"}),
     # round 6: one rank WITHOUT the loopback issues no RCCL call: there the capture forks PosNet's stream (RCCL operations on a
     # forked stream end the capture in a SIGSEGV on ROCm 7.2, with one communicator as with two: profiles/r06_dist_overhead.txt)
-    ("grid", "sharded", "0", "1", "1", {"DDMP_DIST_GRAPH": "1"})])
+    ("grid", "sharded", "0", "1", "1", {"DDMP_DIST_GRAPH": "1"}),
+    # round 6: the communicator's EXCHANGE STREAM (every RCCL call on a stream of its own behind an event of the kernels' stream;
+    # what the interior / boundary overlap rides on) with every call really going through RCCL
+    ("grid", "sharded", "0", "1", "0", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_SPLIT": "1"}),
+    ("ico4", "sharded", "0", "1", "1", {"DDMP_COMM_LOOPBACK": "1", "DDMP_DIST_SPLIT": "1"})])
 def test_rccl_ranks_match_single_device(kind, losses, interleave, native, streams, extra):
     n = min(2, torch.cuda.device_count())                   # counting devices does not initialise the GPU in this process
     assert n >= 1
