@@ -927,10 +927,12 @@ class DistributedTrainer:
                     b.use_xs = True                              # every RCCL call of the communicator on its exchange stream
         self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
                               comm=GraphComm(self.backend_pos, sd.vplan, device), n_total=sd.V,
-                              dtype=getattr(posnet, "feature_dtype", torch.float32), split=halves(sd.vplan))
+                              dtype=getattr(posnet, "feature_dtype", torch.float32), split=halves(sd.vplan),
+                              overlap=getattr(self, "overlap_halo", False))
         self.neng = GcnEngine(fg, NORM_WIDTHS, 1, sd.z2.to(device), None,
                               comm=GraphComm(backend, sd.fplan, device), n_total=sd.F,
-                              dtype=getattr(normnet, "feature_dtype", torch.float32), split=halves(sd.fplan))
+                              dtype=getattr(normnet, "feature_dtype", torch.float32), split=halves(sd.fplan),
+                              overlap=getattr(self, "overlap_halo", False))
         for net, eng in ((posnet, self.peng), (normnet, self.neng)):
             if hasattr(net, "attach_engine"):
                 net.attach_engine(eng)                          # net(data) then runs on this rank's shard

@@ -168,7 +168,7 @@ class GcnEngine:
 
     def __init__(self, graph: ops.Graph, widths: List[int], kind: int, x0: torch.Tensor,
                  x_pos: Optional[torch.Tensor] = None, comm=None, n_total: Optional[int] = None,
-                 perm: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32, split=None):
+                 perm: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32, split=None, overlap: bool = False):
         """``perm`` (int64 [n_rows], new -> old): the engine works on nodes relabelled for gather locality
         (``graph`` and ``x0``/``x_pos`` must already be in the NEW numbering); :meth:`forward` returns and
         :meth:`backward` accepts rows in the caller's ORIGINAL numbering.
@@ -186,8 +186,11 @@ class GcnEngine:
         # aggregation then runs as two launches: the halo exchange of the gathered tensor is STARTED (comm.start_halo_overlapped),
         # the interior rows are aggregated while it travels, the boundary rows behind it; fused column sums of the two halves are
         # added in float64.  The same two launches with the exchange waited for first (DDMP_DIST_OVERLAP=0) give the same bits.
+        # ``overlap`` is the JOB's setting (the same on every rank: it fixes the order in which the collectives are issued), ``split``
+        # this rank's halves -- None where a rank has no interior chunk or no halo: that rank waits and aggregates in one launch.
+        self.overlap = bool(overlap)
         self.split = None
-        if split is not None and comm is not None and 0 < split[2] < graph.n_rows:
+        if self.overlap and split is not None and 0 < split[2] < graph.n_rows:
             self.split = tuple(split)
             self.n_int = int(split[2])
         self._halo_ahead = None
@@ -394,7 +397,21 @@ class GcnEngine:
         return ((g_int, 0, ni, self.sums), (g_bnd, ni, self.n_rows, self.sums_b))
 
     def _add_sums(self, width):
-        self.sums[:width] += self.sums_b[:width]
+        if self.split:
+            self.sums[:width] += self.sums_b[:width]
+
+    def _agg(self, launch, h):
+        """Overlap mode, as a generator: ``launch(graph, r0, r1, sums)`` aggregates rows [r0, r1) (fused column sums into
+        ``sums``); ``h`` = the started exchange of the gathered tensor's halo rows.  Interior rows, wait, boundary rows -- or,
+        on a rank without halves, wait and one launch."""
+        if self.split:
+            for k, (gh, r0, r1, sums) in enumerate(self._halves()):
+                if k == 1:
+                    yield h
+                launch(gh, r0, r1, sums)
+        else:
+            yield h
+            launch(self.g, 0, self.n_rows, self.sums)
 
     def forward_steps(self, params: torch.Tensor, update_running: bool = True, use_running: bool = False):
         """The forward pass as a generator that yields at every collective it STARTS (halo exchange, BatchNorm
@@ -420,13 +437,10 @@ class GcnEngine:
                                    running=(self.running[l][0], self.running[l][1]) if update_running else None)} if tail else {}
             if self.agg_first[l]:
                 P = self.P[l]
-                if self.split and l > 0:
+                if self.overlap and l > 0:
                     h = self._halo_ahead if halo_started else self._start_halo(X)
                     self._halo_ahead = None
-                    for k, (gh, r0, r1, _) in enumerate(self._halves()):
-                        if k == 1:
-                            yield h
-                        ops.spmm(gh, X, out=P[r0:r1], pro=pro)
+                    yield from self._agg(lambda gh, r0, r1, _: ops.spmm(gh, X, out=P[r0:r1], pro=pro), h)
                 elif l > 0 or not self._p1_ready:
                     if l > 0 and not halo_started:
                         yield comm.start_halo(X, n)
@@ -440,18 +454,13 @@ class GcnEngine:
             else:
                 H = self._work(0, L.cout[l])
                 ops.gemm_nt(X, W, out=H, pro=pro, n_rows=n, **self._wp(l, 0), **self._scales(l, 0))
-                if self.split:
-                    h = self._start_halo(H)
-                    for k, (gh, r0, r1, sums) in enumerate(self._halves()):
-                        if k == 1:
-                            yield h
-                        if self.fuse_spmm_stats[l]:
-                            ops.spmm_stats(gh, H, Y[r0:r1], self.bn4[l][2], sums, bias=b)
-                        else:
-                            ops.spmm(gh, H, out=Y[r0:r1], bias=b)
+                if self.overlap:
                     if self.fuse_spmm_stats[l]:
+                        yield from self._agg(lambda gh, r0, r1, sums: ops.spmm_stats(gh, H, Y[r0:r1], self.bn4[l][2], sums, bias=b),
+                                             self._start_halo(H))
                         self._add_sums(2 * L.cout[l])
                     else:
+                        yield from self._agg(lambda gh, r0, r1, _: ops.spmm(gh, H, out=Y[r0:r1], bias=b), self._start_halo(H))
                         ops.bn_stats(Y, sums=self.sums, n_rows=n, **bnk)
                 else:
                     yield comm.start_halo(H, n)
@@ -463,8 +472,8 @@ class GcnEngine:
             # the halo rows of Y (raw, pre-BatchNorm: the consumer applies the prologue) do not depend on the statistics:
             # when the next layer gathers Y directly, its halo exchange travels together with the all-reduce
             halo_started = l < 11 and self.agg_first[l + 1]
-            fused = None if self.split else getattr(comm, "halo_and_sums", None)
-            if self.split:
+            fused = None if self.overlap else getattr(comm, "halo_and_sums", None)
+            if self.overlap:
                 # the sums first (the next kernel's prologue needs them), the halo rows of Y behind them and beside the
                 # interior rows' aggregation of the next layer
                 yield comm.start_all_reduce(self.sums[: 2 * L.cout[l]])
@@ -574,18 +583,14 @@ class GcnEngine:
             return False
 
         def spmm_to_dz_split(src, dst, l):
-            """The same in split mode, as a generator: exchange started, interior rows, wait, boundary rows."""
-            h = self._start_halo(src)
+            """The same in overlap mode, as a generator: exchange started, interior rows, wait, boundary rows."""
             red = fuse_red and l > 0
-            for k, (gh, r0, r1, sums) in enumerate(self._halves()):
-                if k == 1:
-                    yield h
-                if red:
-                    ops.spmm_bnred(gh, src, dst[r0:r1], self.Y[l - 1][r0:r1], self.bn4[l - 1], sums)
-                else:
-                    ops.spmm(gh, src, out=dst[r0:r1])
             if red:
+                yield from self._agg(lambda gh, r0, r1, sums: ops.spmm_bnred(gh, src, dst[r0:r1], self.Y[l - 1][r0:r1],
+                                                                            self.bn4[l - 1], sums), self._start_halo(src))
                 self._add_sums(2 * L.cout[l - 1])
+            else:
+                yield from self._agg(lambda gh, r0, r1, _: ops.spmm(gh, src, out=dst[r0:r1]), self._start_halo(src))
             return red
 
         # transform-first dgrads with the next BatchNorm-backward reductions in their epilogue (row-register kernel, float32).
@@ -628,7 +633,7 @@ class GcnEngine:
                 # the BatchNorm passes that follow
                 wgrad(l, lambda: ops.gemm_tn_bnbwd(dZ, Y, self.P[l], bn4, c10, out=dW, n_rows=n, **self._scales(l, 1, 0)), kz)
                 release(kz)
-                if self.split:
+                if self.overlap:
                     kz, dZ = take(ci)
                     have_sums = yield from spmm_to_dz_split(dP, dZ, l)
                 else:
@@ -666,7 +671,7 @@ class GcnEngine:
                 wgrad(l, lambda: ops.gemm_tn(dY, self.P[l], out=dW, n_rows=n, **self._scales(l, 1, 0)), ky)
                 if l > 0:
                     release(ky)
-                    if self.split:
+                    if self.overlap:
                         kz, dZ = take(ci)
                         have_sums = yield from spmm_to_dz_split(dP, dZ, l)
                     else:
@@ -677,13 +682,10 @@ class GcnEngine:
                 else:
                     release(ky)
             else:
-                if self.split:
+                if self.overlap:
                     h = self._start_halo(dY)
                     kh, dH = take(co)
-                    for k, (gh, r0, r1, _) in enumerate(self._halves()):
-                        if k == 1:
-                            yield h
-                        ops.spmm(gh, dY, out=dH[r0:r1])
+                    yield from self._agg(lambda gh, r0, r1, _: ops.spmm(gh, dY, out=dH[r0:r1]), h)
                 else:
                     yield comm.start_halo(dY, n)
                     kh, dH = take(co)

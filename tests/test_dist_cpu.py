@@ -234,7 +234,7 @@ def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated"):
             _sharded_rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, results, epoch0=0)
         else:
             _rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, oracle, results)
-        out, pa, na = results[rank]
+        out, pa, na = results[rank][:3]
         q.put((rank, [(l, p.numpy(), n.numpy()) for l, p, n in out], pa.numpy(), na.numpy()))
         dist.barrier()
         dist.destroy_process_group()
