@@ -692,7 +692,6 @@ def main():
         if hasattr(tr, "use_graph"):
             tr.use_graph = False             # per-launch events need the eager path
             tr.overlap = False
-            tr.peng.async_wgrad = tr.neng.async_wgrad = False
         tr.step().item()
         ops.PROF = ops.Profiler()
         torch.cuda.synchronize()

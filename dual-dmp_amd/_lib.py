@@ -108,5 +108,4 @@ def status_string(st: int) -> str:
 
 def check(st: int, what: str = ""):
     if st != 0:
-        lib().ddmp_next_cancel()         # nothing armed for "the next call" survives an error (include/ddmp_hip.h, ABI 2)
         raise DdmpError("%s failed: status %d (%s)" % (what or "ddmp call", st, status_string(st)))

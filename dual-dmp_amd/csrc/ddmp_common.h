@@ -5,6 +5,20 @@
 #include <stddef.h>
 
 #include "../../include/ddmp_hip.h"
+#include "ddmp_internal.h"
+#ifdef __cplusplus
+#include <cstdlib>
+#include <string>
+namespace ddmp {
+// DDMP_UNFUSE=name[,name...]: fused routes switched OFF for A/B runs and the fused-vs-composed identity tests (read once per
+// process; the host mirror reads the same variable: dual-dmp_amd/ops.py `unfused`).  Names used in the library: bnbwd_narrow,
+// dgrad_red_narrow; in the engine: stats, gather_bwd, bnbwd_l0, dgrad_red, tail, wprep, bf16_gemm, bf16_spmm_red, equal_width.
+inline bool unfused(const char* name) {
+    static const std::string v = [] { const char* e = getenv("DDMP_UNFUSE"); return std::string(",") + (e ? e : "") + ","; }();
+    return v.size() > 2 && v.find(std::string(",") + name + ",") != std::string::npos;
+}
+}  // namespace ddmp
+#endif
 
 #define HIP_TRY(expr)                                  \
     do {                                               \

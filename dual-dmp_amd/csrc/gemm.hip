@@ -338,14 +338,13 @@ bool tn_panel_enabled();
 int64_t tn_panel_min_rows();
 
 // narrow_panels: the caller takes the f16x3 route of gemm_tn_rm.hip, which also has 256 x 128 and 128 x 256 panels (the
-// 128 <-> 256 layers; DDMP_TN_NARROW_PANELS=0: those stay on the tiled bf16x6 kernel, A/B)
+// 128 <-> 256 layers)
 TnPlan tn_plan(int64_t n_rows, int M, int K, bool narrow_panels = false) {
     TnPlan p;
     p.T = (M >= 128 && K >= 128) ? 2 : 1;
     p.tm = p.tk = 0;
-    static const bool narrow_on = [] { const char* e = getenv("DDMP_TN_NARROW_PANELS"); return !(e && atoi(e) == 0); }();
     const bool wide = M >= 256 && K >= 256;
-    const bool narrow = narrow_panels && narrow_on && ((M >= 256 && K == 128) || (M == 128 && K >= 256));
+    const bool narrow = narrow_panels && ((M >= 256 && K == 128) || (M == 128 && K >= 256));
     if ((wide || narrow) && n_rows >= tn_panel_min_rows() && tn_panel_enabled()) {
         p.T = 4;
         p.tm = M >= 256 ? 256 : 128;
@@ -412,15 +411,7 @@ static int device_cus() {
     return n;
 }
 
-// DDMP_GEMM_WS=0 keeps the one-role-per-wave kernel (A/B comparisons)
-static bool ws_enabled() {
-    static int e = -1;
-    if (e < 0) {
-        const char* v = getenv("DDMP_GEMM_WS");
-        e = (v && atoi(v) == 0) ? 0 : 1;
-    }
-    return e == 1;
-}
+static bool ws_enabled() { return true; }
 
 // ---------------------------------------------------------------- weights prepared once per iteration (round 3)
 // Every GEMM call used to split its weight matrix into 16-bit planes itself: absolute maximum (memset + kernel) + split
@@ -642,8 +633,7 @@ static void launch_panel(int mode, const float* A, int64_t lda, const float* A2,
         // PM = 2 with two column halves (512 <- 512 dgrad): the halves are separate, freely drifting workgroups and BOTH stream
         // (dZ, Y) -- PMC: the family read 27.3 GB per step for 18.4 GB algorithmic, the second half's rows mostly missing the
         // XCD's L2 -- while the row-panel kernel reads them once at the same speed (1499 vs 1490-1511 us): that shape keeps it.
-        static const bool rr_pm2_wide = env_rows("DDMP_RR_PM2_WIDE", 0) == 1;
-        const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0) && !(PM == 2 && MD > kRRCols && !rr_pm2_wide);
+        const bool rr = rr_route_ok(n_rows, KD, lda, PM == 2 ? lda2 : 0) && !(PM == 2 && MD > kRRCols);
         if (!w_ready)
             hipLaunchKernelGGL((split_w_panel_kernel<2, _Float16>), dim3(sgrid), dim3(256), 0, st, W, ldw, MD, KD, transpose, MP,
                                (_Float16*)planes, (const float*)wscale);
@@ -1132,7 +1122,7 @@ extern "C" int ddmp_gemm_nn_bnred_supported(int M, int K, int64_t n_rows) {
     if (gemm_mode() == 6 && gemm_f16() && rr_enabled() && panel_enabled() && n_rows >= kRRMinRows && M % 32 == 0 && M >= 64 &&
         M <= kMaxProK && K > 128 && K <= 512 && K % 4 == 0)
         return 1;                                                // wide outputs: row-register kernel, STATS = 2
-    static const bool narrow = [] { const char* e = getenv("DDMP_GEMM_BNRED_NARROW"); return !(e && atoi(e) == 0); }();   // (A/B)
+    static const bool narrow = !ddmp::unfused("dgrad_red_narrow");   // (A/B)
     // narrow outputs (128 | 64 columns): the 512-row panel kernel's RS epilogue (bf16 split terms)
     return (narrow && (gemm_mode() == 6 || gemm_mode() == 3) && panel_enabled() && n_rows >= kPanelMinRows && M % 32 == 0 &&
             M >= 32 && M <= kMaxProK && (K == 128 || K == 64)) ? 2 : 0;
@@ -1164,7 +1154,7 @@ extern "C" int ddmp_gemm_bnbwd_supported(int cout, int cin, int64_t n_rows) {
     // (round 3: 32 -> 64 ... 128 -> 256): the 512-row panel dgrad and the tiled wgrad with the same operand prologue
     const bool nn = cout % 32 == 0 && cout >= 64 && cout <= kMaxProK && cin % 4 == 0 && cin >= 16 && cin <= 512;
     const bool tn = cout % 4 == 0 && ((cout >= 256 && cin >= 256) || cin <= 128);
-    static const bool narrow = [] { const char* e = getenv("DDMP_BNBWD_NARROW"); return !(e && atoi(e) == 0); }();   // (A/B)
+    static const bool narrow = !ddmp::unfused("bnbwd_narrow");   // (A/B)
     return (nn && tn && (cin > 128 || narrow)) ? 1 : 0;
 }
 

@@ -796,8 +796,7 @@ template <bool BWD>
 int launch_rr_b16(const bf16_t* A, int64_t lda, const bf16_t* A2, int64_t lda2, const float* W, int64_t ldw, int transpose,
                   bf16_t* Y, int64_t ldy, int64_t n_rows, int KD, int MD, const float* bias, const float* ps, const float* psh,
                   const float* pc1, const float* pc0, float slope, void* ws, size_t ws_bytes, void* stats_ws,
-                  size_t stats_ws_bytes, double* sums, hipStream_t st, const bf16_t* red_yp = nullptr, int64_t red_ldyp = 0,
-                  const float* const* red_bn4 = nullptr /* scale, shift, mean, rstd: sums = the backward reductions */) {
+                  size_t stats_ws_bytes, double* sums, hipStream_t st) {
     const int MPW = MD > kRBCols ? 512 : 256;
     const size_t need = (size_t)KD * MPW * sizeof(uint16_t);
     if (!ws || ws_bytes < need || !b16_aligned(ws)) return DDMP_EWORKSPACE;
@@ -815,10 +814,6 @@ int launch_rr_b16(const bf16_t* A, int64_t lda, const bf16_t* A2, int64_t lda2, 
     hipLaunchKernelGGL((gemm_rr_b16_kernel<PM_, ST_, NB_>), grid, block, 0, st, A, lda, A2, lda2, planes, MPW, Y, ldy,  \
                        (int)n_rows, KD, MD, bias, ps, psh, pc1, pc0, slope, tiles, stats)
     if (BWD) DDMP_RRB(2, 0, 2);
-    else if (sums && red_yp)
-        hipLaunchKernelGGL((gemm_rr_b16_kernel<0, 2, 3>), grid, block, 0, st, A, lda, A2, lda2, planes, MPW, Y, ldy, (int)n_rows, KD,
-                           MD, bias, ps, psh, pc1, pc0, slope, tiles, stats, red_yp, red_ldyp, red_bn4[0], red_bn4[1], red_bn4[2],
-                           red_bn4[3]);
     else if (sums && ps) DDMP_RRB(1, 1, 3);
     else if (sums) DDMP_RRB(0, 1, 3);
     else if (ps) DDMP_RRB(1, 0, 3);
@@ -930,43 +925,6 @@ extern "C" int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const flo
                                 slope, workspace, workspace_bytes, stats_ws, stats_ws_bytes, sums2, (hipStream_t)stream);
 }
 
-// Transform-first dgrad with the NEXT BatchNorm-backward reductions in its epilogue (round 5; float32: ddmp_gemm_nn_bnred_f32):
-//     out[n, K] = bf16(A[n, M] . W[M, K]),   sums2 = bn_bwd_reduce(out, Yp, scale, shift, mean, rstd)
-// on the row-register kernel.  Measured at 1M faces against the plain dgrad + the bn_bwd_reduce pass (scripts/bf16_bnred_probe.py,
-// scripts/r05_bf16_bnred_ab2.sh; profiles/r05_bf16_bnred_ab.txt): alone it wins at 256 -> 512 (805 vs 917 us on the face graph) and
-// ties at 128 -> 256 (364 vs 379), loses at 64 -> 128 (279 vs 195: two k-steps per tile under this epilogue); INSIDE the step it
-// returns nothing (25.50 / 25.52 ms with the pass, 25.54 / 25.57 ms fused, three interleaved rounds): the pass it removes is a pure
-// streaming kernel that fills the gaps beside the other net's GEMMs, the epilogue's 2-byte strided reads of Yp are not.  So
-// ..._supported says 0 unless DDMP_BF16_GEMM_BNRED=1 (A/B; contractions from DDMP_BF16_GEMM_BNRED_MINM, default 128); the entry
-// point itself takes every shape the row-register kernel takes.
-extern "C" int ddmp_gemm_nn_bnred_bf16_supported(int M, int K, int64_t n_rows) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("DDMP_BF16_GEMM_BNRED");
-        on = (e && atoi(e) == 1) ? 1 : 0;
-    }
-    static int min_m = -1;
-    if (min_m < 0) {
-        const char* e = getenv("DDMP_BF16_GEMM_BNRED_MINM");
-        min_m = (e && atoi(e) > 0) ? atoi(e) : 128;
-    }
-    return on && rr_b16_ok(n_rows, M, K, M, 0) && M >= min_m ? 1 : 0;
-}
-
-extern "C" int ddmp_gemm_nn_bnred_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out,
-                                       int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale,
-                                       const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
-                                       void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
-                                       ddmp_stream stream) {
-    ddmp::FinalizeScope fin_scope(sums2, stream, K);
-    ARG_TRY(A && W && out && Yp && scale && shift && mean && rstd && sums2 && n_rows > 0 && n_rows < INT32_MAX && M > 0 && K > 0);
-    ARG_TRY(ldw >= K && lda >= M && ld_out >= K && ldyp >= K && lda % 8 == 0 && ld_out % 8 == 0 && b16_aligned(A) && b16_aligned(out));
-    if (!rr_b16_ok(n_rows, M, K, lda, 0)) return DDMP_EINVAL;
-    const float* bn4[4] = {scale, shift, mean, rstd};
-    return launch_rr_b16<false>(A, lda, nullptr, 0, W, ldw, 1, out, ld_out, n_rows, M, K, nullptr, nullptr, nullptr, nullptr, nullptr,
-                                slope, workspace, workspace_bytes, stats_ws, stats_ws_bytes, sums2, (hipStream_t)stream, Yp, ldyp, bn4);
-}
-
 // out[n, K] = bf16(dY) . W[M, K] with dY = BatchNorm+LeakyReLU backward of (dZ, Yb) rebuilt on the operand load
 extern "C" int ddmp_gemm_nn_bnbwd_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb, const float* W,
                                        int64_t ldw, uint16_t* out, int64_t ld_out, int64_t n_rows, int M, int K,
@@ -1035,11 +993,7 @@ extern "C" int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t*
     const int64_t sstride = (int64_t)M * K;
     const int n_tiles = p.n_tiles_m * p.n_tiles_k;
     dim3 grid((unsigned)(cdiv(p.n_splits, kXcd) * kXcd * n_tiles)), block(512);
-    static int tn_dma = -1;                                      // DDMP_TN_DMA=0: the register-staged kernel for every wgrad (A/B)
-    if (tn_dma < 0) {
-        const char* e = getenv("DDMP_TN_DMA");
-        tn_dma = (e && atoi(e) == 0) ? 0 : 1;
-    }
+    constexpr int tn_dma = 1;                                    // (0: the register-staged kernel for every wgrad -- an A/B of round 3)
     if (pro_scale)
         hipLaunchKernelGGL((gemm_tn_b16_kernel<true>), grid, block, 0, st, G, ldg, Z, ldz, part, (int64_t)K, sstride,
                            (int)n_rows, M, K, p.rows_per_split, p.n_tiles_m, p.n_tiles_k, p.n_splits, pro_scale, pro_shift, slope);

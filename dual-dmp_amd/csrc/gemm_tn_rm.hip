@@ -450,8 +450,8 @@ void launch_tn_rm(const TnRmArgs& a, hipStream_t st) {
     const int n_tiles = a.n_tiles_m * a.n_tiles_k;
     dim3 grid((unsigned)(cdiv(a.n_splits, kXcd) * kXcd * n_tiles)), block(512);
     const bool pro = a.pscale != nullptr, gdual = a.G2 != nullptr;
-    // DDMP_TN_PP=0: the same segment order on all waves (A/B; measured 6-9 % slower: profiles/r04_tn_kernel_ab.txt)
-    static const int pp = [] { const char* e = getenv("DDMP_TN_PP"); return e ? atoi(e) : 1; }();
+    // (pp = 0: the same segment order on all waves; measured 6-9 % slower: profiles/r04_tn_kernel_ab.txt)
+    constexpr int pp = 1;
 #define DDMP_L3_(P_, G_, Q_, TM_, TK_) hipLaunchKernelGGL((gemm_tn_rm_kernel<P_, G_, Q_, TM_, TK_>), grid, block, 0, st, a)
 #define DDMP_L_(P_, G_, Q_)                                                                       \
     do {                                                                                          \

@@ -155,8 +155,7 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
         // any more (round 5): long rows run their tail from LDS lists, oversized chunks go to the heavy list.
         const char* pe = getenv("DDMP_SPMM_PATCH");
         const int pm = pe ? atoi(pe) : 3;
-        const char* mr = getenv("DDMP_SPMM_PATCH_MIN_ROWS");
-        const int64_t min_rows = mr ? atoll(mr) : 65536;
+        const int64_t min_rows = 65536;                          // (16384 measured no gain at 62,500 rows: profiles/r06_launch_bound_probes.txt)
         bool ok = g->nnz > 0 && (pm == 1 || (pm != 0 && g->nnz <= 12 * n_rows && n_rows >= min_rows));
         constexpr int kMaxE = ddmp::kChunkRows * 16, kMaxKd = 6;
         std::vector<int32_t> np_of, tmp;

@@ -89,11 +89,6 @@ extern "C" int ddmp_gemm_nn_bnred_f32_o(const float* A, int64_t lda, const float
     return ddmp_gemm_nn_bnred_f32(A, lda, W, ldw, out, ld_out, n_rows, M, K, Yp, ldyp, scale, shift, mean, rstd, slope, sums2, workspace, workspace_bytes, stats_ws, stats_ws_bytes, stream);
 }
 
-extern "C" int ddmp_gemm_nn_bnred_bf16_o(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out, int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts) {
-    OptScope scope(opts);
-    if (scope.err) return scope.err;
-    return ddmp_gemm_nn_bnred_bf16(A, lda, W, ldw, out, ld_out, n_rows, M, K, Yp, ldyp, scale, shift, mean, rstd, slope, sums2, workspace, workspace_bytes, stats_ws, stats_ws_bytes, stream);
-}
 
 extern "C" int ddmp_gemm_nn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw, float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b, const float* c1, const float* c0, float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts) {
     OptScope scope(opts);

@@ -384,8 +384,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
     // workgroups exist -- a workgroup per 64 rows alone leaves a 13k-row graph with 205 long-running workgroups on 256 CUs
     int groups = 1;
     const int n_slabs = C / 32;
-    static const bool split_on = [] { const char* e = getenv("DDMP_SPMM_SLAB_GROUPS"); return !(e && atoi(e) == 0); }();   // (A/B)
-    if (split_on && lp.n_chunks < 1024 && n_slabs > 1) {
+    if (lp.n_chunks < 1024 && n_slabs > 1) {
         const int want = std::min(n_slabs, std::max(1, 2048 / std::max(lp.n_chunks, 1)));
         const int per = (n_slabs + want - 1) / want;
         groups = (n_slabs + per - 1) / per;
@@ -448,12 +447,7 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16 == 0) &&
                      (!bias || reinterpret_cast<uintptr_t>(bias) % 16 == 0) &&
                      (!pro_scale || (reinterpret_cast<uintptr_t>(pro_scale) | reinterpret_cast<uintptr_t>(pro_shift)) % 16 == 0);
-    static int spmm_mode = -1;                       // DDMP_SPMM=row selects the row kernel for every width
-    if (spmm_mode < 0) {
-        const char* e = getenv("DDMP_SPMM");
-        spmm_mode = (e && e[0] == 'r') ? 0 : (e && e[0] == 's' && e[1] == '1') ? 5 : 4;      // default: slab / lean kernels
-    }
-    if (vec && spmm_mode >= 4 && C % 32 == 0) {                  // LDS-patch kernel (spmm_patch.hip) where it applies
+    if (vec && C % 32 == 0) {                  // LDS-patch kernel (spmm_patch.hip) where it applies
         const LeanPlan lp = lean_plan(g, ldx, ldy, C);           // (its heavy chunks are the lean gather's)
         if (lp.kind || g->n_heavy == 0) {
             const int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_F32, bias, pro_scale, pro_shift, slope, nullptr, 0, nullptr,
@@ -466,23 +460,12 @@ extern "C" int ddmp_spmm_f32(const ddmp_graph* g, const float* X, int64_t ldx, f
             if (rc != ddmp::kPatchNotApplicable) return rc;
         }
     }
-    if (vec && spmm_mode >= 4 && C >= 32 && C % 32 == 0) {
-        // 4 gathers in flight per lane measured best (8 in flight -- one batch of 8, or two rows x 4 -- was 3-5 %
-        // slower: the kernel is bound by on-chip issue / L1 cost per gathered row, not by memory latency);
-        // DDMP_SPMM=s1 selects the 8-in-flight forms for A/B runs
-        static int slabs = -1;                       // DDMP_SPMM_SL=1|2|4: slabs per pass (A/B)
-        if (slabs < 0) {
-            const char* e2 = getenv("DDMP_SPMM_SL");
-            slabs = e2 ? atoi(e2) : 1;
-        }
-        if (spmm_mode == 4 && slabs == 2 && C % 64 == 0) return launch_slab<8, 4, 1, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        if (spmm_mode == 4 && slabs == 4 && C % 128 == 0) return launch_slab<8, 4, 1, 4>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        if (spmm_mode == 4 && slabs == 22 && C % 64 == 0) return launch_slab<8, 2, 1, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        if (spmm_mode == 4) return launch_slab<8, 4, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        if (g->max_row_nnz <= 4) return launch_slab<8, 4, 2>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
-        return launch_slab<8, 8, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
+    if (vec && C >= 32 && C % 32 == 0) {
+        // 4 gathers in flight per lane, one 128-byte slab per pass (8 in flight -- one batch of 8, or two rows x 4 -- and two / four
+        // slabs per pass measured 3-5 % slower in rounds 2-3: bound by on-chip issue / L1 cost per gathered row, not by latency)
+        return launch_slab<8, 4, 1>(g, X, ldx, Y, ldy, C, bias, pro_scale, pro_shift, slope, st);
     }
-    if (vec) {
+    if (vec) {                                                   // (widths below one 128-byte slab)
         switch (C) {
             case 8: return launch_vec<2, 1>(g, X, ldx, Y, ldy, bias, pro_scale, pro_shift, slope, st);
             case 16: return launch_vec<4, 1>(g, X, ldx, Y, ldy, bias, pro_scale, pro_shift, slope, st);

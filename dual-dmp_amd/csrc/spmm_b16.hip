@@ -388,22 +388,8 @@ template <bool PRO, int RED, bool BWD>
 int dispatch_b16(const ddmp_graph* g, const bf16_t* X, int64_t ldx, bf16_t* Y, int64_t ldy, int C, const float* bias,
                  const float* ps, const float* psh, float slope, hipStream_t st, BnRedB red = BnRedB(),
                  BnBwdGatherB bwd = BnBwdGatherB(), const int* heavy = nullptr, int n_heavy = 0) {
-    // DDMP_SPMM_B16_VW=4 (A/B): 8-byte pieces in the fused forms.  Measured SLOWER although it restores full occupancy
-    // (1M-face graph, C = 512: prologue form 771 vs 613 us, reduction form 1043 vs 999 us): these forms are bound by
-    // instructions issued per gathered byte (index / weight reads, 64-bit addresses, unpack + 4 VALU per element), and
-    // halving the piece doubles the per-gather part.
-    static int vw_fused = -1;
-    if (vw_fused < 0) {
-        const char* e = getenv("DDMP_SPMM_B16_VW");
-        vw_fused = (e && atoi(e) == 4) ? 4 : 8;
-    }
-    constexpr bool kFused = PRO || RED != 0 || BWD;
-    if (kFused && vw_fused == 4) {
-        if (C % 64 == 0) return launch_b16<4, 16, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
-        if (C % 32 == 0) return launch_b16<4, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
-        if (C % 16 == 0) return launch_b16<4, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
-        return launch_b16<4, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
-    }
+    // (8-byte pieces in the fused forms measured SLOWER although they restore full occupancy -- 1M-face graph, C = 512: prologue form
+    // 771 vs 613 us, reduction form 1043 vs 999 us: these forms are bound by instructions issued per gathered byte.)
     if (C % 64 == 0) return launch_b16<8, 8, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
     if (C % 32 == 0) return launch_b16<8, 4, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);
     if (C % 16 == 0) return launch_b16<8, 2, PRO, RED, BWD>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red, bwd, heavy, n_heavy);

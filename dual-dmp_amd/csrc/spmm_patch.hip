@@ -369,14 +369,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
 }
 
-int patch_nb() {                                                  // DDMP_SPMM_PATCH_NB=2|4 (A/B)
-    static int nb = 0;
-    if (!nb) {
-        const char* e = getenv("DDMP_SPMM_PATCH_NB");
-        nb = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 3) ? 3 : 2;
-    }
-    return nb;
-}
+// (two LDS buffers: three and four measured slower, profiles/r02_experiments)
 
 template <typename T, int KD, bool PRO, int RED, int NB>
 size_t patch2_lds(int C) {
@@ -422,11 +415,6 @@ int patch_ne() {                                                  // DDMP_SPMM_P
 template <typename T, int KD, bool PRO, int RED>
 int launch_patch2(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
                   const float* psh, float slope, hipStream_t st, RedArgs red) {
-    // (the A/B buffer counts keep the LDS-entry form)
-    if constexpr (!RED) {
-        if (patch_nb() == 4) return launch_patch2nb<T, KD, PRO, RED, 4, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-        if (patch_nb() == 3) return launch_patch2nb<T, KD, PRO, RED, 3, 0>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
-    }
     // register entries: 4 where no row has more (face graphs), else 8 with the longer rows' tails from LDS (round 5)
     if (patch_ne() && g->max_row_nnz <= 4) return launch_patch2nb<T, KD, PRO, RED, 2, 4>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
     if (patch_ne()) return launch_patch2nb<T, KD, PRO, RED, 2, 8>(g, X, ldx, Y, ldy, C, bias, ps, psh, slope, st, red);
@@ -454,10 +442,7 @@ int by_patch(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, in
 // (before the entries moved to registers the vertex graph lost everywhere: 583 / 277 us plain).  Round 5 (RCB numbering, patch_forms
 // below): every form from C = 256 wins or ties.  DDMP_SPMM_PATCH: unset = the measured selection (ddmp_spmm_patch_selected), 0 =
 // never, 1 = wherever it applies (A/B runs).
-int patch_max_nnz() {                                             // DDMP_SPMM_PATCH_MAXNNZ=5: the face graph only (A/B)
-    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_MAXNNZ"); return (e && atoi(e) > 0) ? atoi(e) : (1 << 30); }();
-    return v;
-}
+constexpr int patch_max_nnz() { return 1 << 30; }
 int patch_mode() {
     static int m = -1;
     if (m < 0) {
@@ -470,15 +455,12 @@ int patch_mode() {
 
 }  // namespace
 
-// DDMP_SPMM_PATCH_FORMS (A/B, default 15): bit 0 the prologue form at C >= 512, bit 1 the fused BatchNorm-backward reduction, bit 2
+// Forms taken (all four bits since round 5): bit 0 the prologue form at C >= 512, bit 1 the fused BatchNorm-backward reduction, bit 2
 // the fused statistics form on the LDS-patch kernel (all from C = 256), bit 3 bfloat16 features on it (plain, prologue, statistics) -- round 5, measured with the RCB numbering (smaller
 // patches: KD = 5 instead of 6, one more workgroup per CU), 1M faces, us per launch patch | lean (profiles/r05_gather_forms.txt):
 //   prologue C = 512 face 812 | 935, vertex 498 | 627;  reduction C = 512 face 1246 | 1284, vertex 707 | 747, C = 256 face
 //   639 | 646, vertex 370 | 394;  statistics C = 512 face 857 | 937, vertex 505 | 616, C = 256 face 432 | 469, vertex 264 | 308
-int patch_forms() {
-    static const int v = [] { const char* e = getenv("DDMP_SPMM_PATCH_FORMS"); return e ? atoi(e) : 15; }();
-    return v;
-}
+constexpr int patch_forms() { return 15; }
 
 // does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
 // has_red: 0 | 1 the BatchNorm-backward reductions | 2 the statistics form

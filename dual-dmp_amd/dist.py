@@ -837,8 +837,8 @@ class DistributedTrainer:
                  k=(3.0, 4.0, 4.0, 4.0, 1.0), grad_crip=0.8, bnfloop=1, betas=(0.9, 0.999), eps=1e-8,
                  bnf_start_epoch=100, ops_mod=None, loss_engine=None, losses=None, backend_pos=None, use_graph=None,
                  overlap_halo=None):
-        """``overlap_halo`` (default: on with more than one rank, env DDMP_DIST_SPLIT=0 switches it off, =1 forces it at one rank
-        too): every aggregation runs as two launches -- the rows that reference no halo row (HaloPlan.n_int: the leading chunks of
+        """``overlap_halo`` (default: on with more than one rank; env DDMP_DIST_SPLIT=0 switches it off, =1 forces it at one rank
+        too, =noverlap keeps the two launches but waits for every exchange first -- the bit-identity check): every aggregation runs as two launches -- the rows that reference no halo row (HaloPlan.n_int: the leading chunks of
         the interior-first local order) while the layer's halo exchange travels on the communicator's exchange stream, the
         boundary rows behind it (engine.GcnEngine ``split``).  Eager path only: a captured iteration keeps whole-graph launches.
 
@@ -880,10 +880,8 @@ class DistributedTrainer:
             # second communicator in the same capture ends in a SIGSEGV (two streams) or never returns (one stream), and -- round
             # 6 -- so does ONE communicator whose operations are captured on two forked streams (SIGSEGV inside the capture): RCCL
             # operations cannot be captured on a forked stream here.  Two streams under capture are therefore taken only where
-            # no RCCL call is issued at all (one rank without DDMP_COMM_LOOPBACK: 8.02 instead of 8.30 ms at 125k faces);
-            # DDMP_DIST_GRAPH_STREAMS=1|2 overrides.
-            quiet = backend.world_size == 1 and os.environ.get("DDMP_COMM_LOOPBACK") != "1"
-            want2 = os.environ.get("DDMP_DIST_GRAPH_STREAMS", "2" if quiet else "1") == "2"
+            # no RCCL call is issued at all (one rank without DDMP_COMM_LOOPBACK: 8.02 instead of 8.30 ms at 125k faces).
+            want2 = backend.world_size == 1 and os.environ.get("DDMP_COMM_LOOPBACK") != "1"
             backend_pos = backend if want2 else None
         if overlap_halo is None:
             e = os.environ.get("DDMP_DIST_SPLIT")
@@ -895,7 +893,6 @@ class DistributedTrainer:
         self._graphs, self._warm = {}, False
         if self.use_graph:
             self.interleaved = False
-            self.peng.async_wgrad = self.neng.async_wgrad = False      # (never a third stream inside the capture)
             self._t_dev = torch.zeros(1, dtype=torch.int32, device=device)
             self._coef = [torch.zeros(2, dtype=torch.float32, device=device) for _ in range(2)]
 
@@ -982,8 +979,6 @@ class DistributedTrainer:
         # path has only run at world size 1 on RCCL and through gloo on CPU (no multi-GPU box in the build loop);
         # the default is the blocking form, which the threaded-rank GPU tests exercise kernel for kernel.
         self.interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "0") == "1"
-        if torch.device(device).type == "cuda" and os.environ.get("DDMP_ASYNC_WGRAD") == "1":
-            self.peng.async_wgrad = self.neng.async_wgrad = True    # opt-in: weight gradients beside the dgrad chain
 
     def barrier(self):
         self.backend.barrier()

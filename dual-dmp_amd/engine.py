@@ -34,6 +34,12 @@ import torch
 from . import ops
 from .ops import SLOPE
 
+def _unfused(name):
+    """ops.unfused (DDMP_UNFUSE), tolerant of the CPU tests' stand-in of ops."""
+    f = getattr(ops, "unfused", None)
+    return bool(f and f(name))
+
+
 POS_WIDTHS = [16, 32, 64, 128, 256, 256, 512, 512, 256, 256, 128, 64, 32, 16, 3]    # util/networks.py:13
 NORM_WIDTHS = [7, 32, 64, 128, 256, 256, 512, 512, 256, 256, 128, 64, 32, 16, 3]    # util/networks.py:74
 
@@ -185,7 +191,7 @@ class GcnEngine:
         # reference no halo row -- and [n_int, n_rows) as graphs of their own (ops.Graph.from_csr_host(rows=...)).  Every
         # aggregation then runs as two launches: the halo exchange of the gathered tensor is STARTED (comm.start_halo_overlapped),
         # the interior rows are aggregated while it travels, the boundary rows behind it; fused column sums of the two halves are
-        # added in float64.  The same two launches with the exchange waited for first (DDMP_DIST_OVERLAP=0) give the same bits.
+        # added in float64.  The same two launches with the exchange waited for first (DDMP_DIST_SPLIT=noverlap) give the same bits.
         # ``overlap`` is the JOB's setting (the same on every rank: it fixes the order in which the collectives are issued), ``split``
         # this rank's halves -- None where a rank has no interior chunk or no halo: that rank waits and aggregates in one launch.
         self.overlap = bool(overlap)
@@ -209,8 +215,8 @@ class GcnEngine:
         self.x_pos = None if x_pos is None else x_pos[:self.n_rows].contiguous().to(torch.float32)
         # aggregate on the narrower side; equal widths aggregate first too: then dY feeds only GEMMs and, where the
         # fused kernels exist, is rebuilt on their operand loads instead of being written by bn_bwd_apply
-        # (DDMP_EQUAL_WIDTH=transform: equal widths transform first, the reference's own order -- A/B)
-        eq_agg = os.environ.get("DDMP_EQUAL_WIDTH", "agg") != "transform"
+        # (DDMP_UNFUSE=equal_width: equal widths transform first, the reference's own order -- A/B)
+        eq_agg = not _unfused("equal_width")
         self.agg_first = [L.cin_p[l] < L.cout[l] or (eq_agg and L.cin_p[l] == L.cout[l]) for l in range(12)]
         supported = getattr(ops, "gemm_bnbwd_supported", None)
         def _bnbwd_ok(l):
@@ -219,14 +225,14 @@ class GcnEngine:
             if dtype == torch.float32:
                 return supported(L.cout[l], L.cin_p[l], self.n_rows)
             try:                                                 # bf16 features: row-register kernel (round 3)
-                return supported(L.cout[l], L.cin_p[l], self.n_rows, dtype) and os.environ.get("DDMP_BF16_FUSE", "1") != "0"
+                return supported(L.cout[l], L.cin_p[l], self.n_rows, dtype) and not _unfused("bf16_gemm")
             except TypeError:                                    # (a stand-in of ops without the dtype argument)
                 return False
         self.fuse_bnbwd = [bool(_bnbwd_ok(l)) for l in range(12)]
         # layer 0 (no dgrad): its dY feeds the wgrad only
         tn_ok = getattr(ops, "gemm_tn_bnbwd_supported", None)
         self.fuse_bnbwd0 = bool(tn_ok and self.agg_first[0] and tn_ok(L.cout[0], L.cin_p[0], self.n_rows, dtype)
-                                and os.environ.get("DDMP_BNBWD_L0", "1") != "0")
+                                and not _unfused("bnbwd_l0"))
         # transform-first layers (l > 0 always: C_in > C_out) on ONE device: BatchNorm backward rebuilt on the SpMM's
         # gather.  Across devices the halo rows of Y_l would have to travel as well (they are not exchanged forward).
         # bf16 features: rebuilding dY on the gather reads two rows per CSR entry; measured (scripts/microbench.py spmm
@@ -235,7 +241,7 @@ class GcnEngine:
         gather_ok = getattr(ops, "spmm_bnbwd_supported", None)
         few_entries = dtype == torch.float32 or getattr(graph, "max_row_nnz", 99) <= 4
         self.fuse_gather_bwd = [bool(gather_ok) and isinstance(self.comm, NoComm) and not self.agg_first[l] and l > 0
-                                and gather_ok(L.cout[l]) and few_entries and os.environ.get("DDMP_SPMM_BNBWD", "1") != "0"
+                                and gather_ok(L.cout[l]) and few_entries and not _unfused("gather_bwd")
                                 for l in range(12)]
         cmax = max(L.cout)
         nc = self.n_cols
@@ -250,21 +256,20 @@ class GcnEngine:
         self.bn4 = [torch.zeros((4, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
         # transform-first layers, float32: BatchNorm statistics from the gather's epilogue (ddmp_spmm_stats_f32)
         st_ok = getattr(ops, "spmm_stats_supported", None)
-        # On by default since round 4 (DDMP_SPMM_STATS=0 for A/B): -0.3 ... -0.4 ms per step at 1M faces, the same sign in every
+        # On by default since round 4 (DDMP_UNFUSE=stats for A/B): -0.3 ... -0.4 ms per step at 1M faces, the same sign in every
         # interleaved A/B (round 3: 46.23 -> 46.07, 46.24 -> 45.93; round 4, scripts/layer_order_ab.sh: 46.38 / 46.23 -> 45.95 /
         # 45.93 ms).  The epilogue's work lands in the gather family (+0.6 ms there, -0.7 ms of bn_stats passes) and takes ~0.02
         # off that family's achieved-bandwidth fraction at the same algorithmic bytes -- the step is what is timed.
         # bf16 features: a tie (26.87 / 26.93 vs 26.98 / 26.77 ms), no fused form.
         self.fuse_spmm_stats = [bool(st_ok) and not self.agg_first[l] and st_ok(L.cout[l], dtype)
-                                and os.environ.get("DDMP_SPMM_STATS", "1") != "0" for l in range(12)]
+                                and not _unfused("stats") for l in range(12)]
         self.c10s = [torch.empty((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
-        self.async_wgrad = False                                # weight gradients on a second stream (set by the trainer)
         # weights split into their 16-bit planes once per iteration, all layers in two launches (float32 features)
         self._wplanes = None
         self._prep_weights = (dtype == torch.float32 and hasattr(ops, "gemm_prepare_weights")
-                              and os.environ.get("DDMP_PREP_WEIGHTS", "1") != "0")
+                              and not _unfused("wprep"))
         self._tail_fused = (isinstance(self.comm, NoComm) and hasattr(ops, "BnFwd")
-                            and os.environ.get("DDMP_TAIL_FUSE", "1") != "0")
+                            and not _unfused("tail"))
         # f16 split GEMM modes: one scale slot per layer and GEMM operand (0: the forward operand X, 1: the gradient
         # operand); the kernels record the operand maxima of this iteration, backward() rolls them into the scales
         # of the next one.  The first iteration measures (prime).
@@ -272,7 +277,6 @@ class GcnEngine:
         self._slot = [[self.scale_slots[l, o] for o in range(2)] for l in range(12)]
         self._prime = True
         self._f16 = False
-        self._side = None
         self.sums = torch.empty(2 * cmax, dtype=torch.float64, device=dev)
         self.sums_b = torch.empty(2 * cmax, dtype=torch.float64, device=dev) if self.split else None   # boundary half's sums
         self.running = [torch.zeros((2, L.cout[l]), dtype=torch.float32, device=dev) for l in range(12)]
@@ -327,11 +331,6 @@ class GcnEngine:
         return healed
 
     # ------------------------------------------------------------------ forward
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
-
     @staticmethod
     def _drain(steps):
         for h in steps:
@@ -385,7 +384,7 @@ class GcnEngine:
         """Split mode: the exchange of t's halo rows, started beside the interior rows' aggregation (a handle to wait on)."""
         comm, n = self.comm, self.n_rows
         start = getattr(comm, "start_halo_overlapped", None)
-        if start is None or os.environ.get("DDMP_DIST_OVERLAP", "1") == "0":
+        if start is None or os.environ.get("DDMP_DIST_SPLIT") == "noverlap":
             h = comm.start_halo(t, n)                            # (A/B and bit-identity check: same launches, no overlap)
             if h is not None:
                 h.wait()
@@ -503,29 +502,14 @@ class GcnEngine:
 
     # ------------------------------------------------------------------ backward
     def backward_steps(self, params: torch.Tensor, grads: torch.Tensor, dout: torch.Tensor):
-        """Backward pass as a generator (see forward_steps).
-
-        ``async_wgrad`` (DDMP_ASYNC_WGRAD=1): every weight gradient (a GEMM nothing in this pass waits for) is issued on a
-        further stream, after the dgrad GEMM and beside the kernels that follow (SpMM, BatchNorm passes, the next dgrad).
-        ONE wgrad is in flight at a time: the main stream waits for it right before it forks the next one (or hands out a
-        work buffer it reads), so that every event the main stream waits on is the TAIL of the side stream -- the first
-        form of this (several in flight, buffers guarded by mid-stream events) made hipStreamEndCapture crash."""
+        """Backward pass as a generator (see forward_steps).  (A further stream for the weight gradients -- GEMMs nothing in
+        this pass waits for -- was an option until round 5: -1.6 ... -2.5 ms per step with the round-4 wgrad kernel at 1M faces,
+        nothing at 13k faces, never capturable beside the two nets' streams; removed in round 6: profiles/r04_stream_overlap_ab.txt.)"""
         L, g, n, comm = self.layout, self.g, self.n_rows, self.comm
-        side = self._side_stream() if self.async_wgrad else None
-        free = list(range(len(self._flat)))                     # FIFO: a buffer read by the wgrad in flight is reused last
-        pending = [None]                                        # (completion event, work buffers it reads) of that wgrad
-
-        def join():
-            """ONE wgrad in flight: its completion event is always the tail of the side stream (a captured graph whose
-            main stream waited on events in the MIDDLE of the side stream made hipStreamEndCapture crash)."""
-            if pending[0] is not None:
-                torch.cuda.current_stream().wait_event(pending[0][0])
-                pending[0] = None
+        free = list(range(len(self._flat)))                     # work buffers, FIFO
 
         def take(c):
             k = free.pop(0)
-            if pending[0] is not None and k in pending[0][1]:
-                join()
             return k, self._work(k, c)
 
         def release(k):
@@ -533,18 +517,7 @@ class GcnEngine:
 
         def wgrad(l, fn, *bufs):
             """fn() launches the weight-gradient GEMM of layer l; bufs = work buffers it reads."""
-            if side is None:
-                fn()
-                return
-            join()
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                fn()
-                done = torch.cuda.Event()
-                done.record(side)
-            pending[0] = (done, set(bufs))
+            fn()
 
         kz, dZ = take(32)
         if self.perm is not None:
@@ -570,9 +543,9 @@ class GcnEngine:
         # the backward column reductions from the SpMM epilogue.  bf16 features: the epilogue (one more row stream + 16 cross-lane
         # sums per 128-byte slab) used to cost as much as the separate pass it replaces (C = 512: 939 us fused vs 457 + 390 us);
         # with one partial record per chunk (round 4) the step gains 0.27 ms (26.21 / 26.22 -> 25.97 / 25.92 ms, interleaved):
-        # on by default, DDMP_BF16_SPMM_BNRED=0 for A/B
+        # on by default, DDMP_UNFUSE=bf16_spmm_red for A/B
         fuse_red = hasattr(ops, "spmm_bnred") and (self.dtype == torch.float32
-                                                   or os.environ.get("DDMP_BF16_SPMM_BNRED", "1") != "0")
+                                                   or not _unfused("bf16_spmm_red"))
 
         def spmm_to_dz(src, dst, l):
             """dZ of layer l-1 = A^T src; with its BatchNorm-backward column reductions where the kernel can."""
@@ -597,9 +570,9 @@ class GcnEngine:
         # Measured at 1M faces (interleaved A/B, 10 steps each): 47.49 / 47.35 ms with, 47.75 / 47.78 ms without.  (A first
         # version lost 0.9 ms: the 32 per-column coefficients of the epilogue were hoisted out of the tile loop as invariants and
         # SPILLED the main loop -- scratch reloads inside the counted-vmcnt pipeline; they now live in LDS and
-        # scripts/check_rr_asm.py audits that form too.)  DDMP_GEMM_BNRED=0 for A/B.
+        # scripts/check_rr_asm.py audits that form too.)  DDMP_UNFUSE=dgrad_red for A/B.
         fuse_dgrad_red = (getattr(ops, "gemm_nn_bnred_supported", None) is not None
-                          and os.environ.get("DDMP_GEMM_BNRED", "1") != "0")
+                          and not _unfused("dgrad_red"))
 
         def dgrad_to_dz(dH, W, dZ, l):
             """dZ of layer l-1 = dH . W (transform-first layer l > 0); with that layer's BatchNorm-backward column reductions
@@ -696,7 +669,6 @@ class GcnEngine:
                     have_sums = dgrad_to_dz(dH, W, dZ, l)
                 wgrad(l, lambda: ops.gemm_tn(dH, Xp, out=dW, pro=pro, n_rows=n, **self._scales(l, 1, 0)), kh)
                 release(kh)
-        join()                                                   # the gradients are complete when this pass returns
         if self._f16:
             ops.gemm_scales_roll(self.scale_slots)
             self._prime = False

@@ -7,6 +7,7 @@ No wrapper has a CPU path: a non-CUDA tensor raises.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 import weakref
 
@@ -125,17 +126,18 @@ def get_gemm_mode() -> int:
     return int(_lib.lib().ddmp_get_gemm_mode())
 
 
+def unfused(name: str) -> bool:
+    """DDMP_UNFUSE=name[,name...]: fused routes switched OFF for A/B runs and the fused-vs-composed identity tests (the library
+    reads the same variable: csrc/ddmp_common.h).  Engine names: stats, gather_bwd, bnbwd_l0, dgrad_red, tail, wprep, bf16_gemm,
+    bf16_spmm_red, equal_width; library names: bnbwd_narrow, dgrad_red_narrow."""
+    v = os.environ.get("DDMP_UNFUSE", "")
+    return bool(v) and name in v.split(",")
+
+
 def next_pending() -> int:
-    """Bit mask of what is armed for "the next call" on this host thread (1 BatchNorm coefficients, 2 GEMM scale slots,
-    4 prepared weight planes)."""
+    """Diagnostic: bit mask of per-call options (1 BatchNorm coefficients, 2 GEMM scale slots, 4 prepared weight planes) still
+    recorded for this host thread -- 0 between calls: an ``_o`` entry point sets its options and clears them around its own call."""
     return int(_lib.lib().ddmp_next_pending())
-
-
-def next_cancel():
-    """Drop everything left "for the next call" on this host thread: the deprecated two-step helpers' host-side requests and
-    whatever a foreign caller armed in the library (ABI 2 calls)."""
-    _pending.bn = _pending.scales = None
-    _lib.lib().ddmp_next_cancel()
 
 
 def gemm_forget_planes(planes=None):
@@ -179,26 +181,9 @@ class BnBwd:
         self.outs = (dgamma, dbeta, c10[0], c10[1], None, None)
 
 
-_pending = threading.local()        # the deprecated two-step forms (bn_next_* / gemm_next_scales): kept on the HOST side only
-
-
-def _take(kind):
-    v = getattr(_pending, kind, None)
-    if v is not None:
-        setattr(_pending, kind, None)
-    return v
-
-
 def _mk_opts(bn=None, scales=None, prepared=False, want_bn=False, want_scales=False):
     """-> (address | None, keep-alive) of the ddmp_opts block of ONE call.  scales = (slot_a, slot_b | None, prime).
-    want_bn / want_scales: this call is of the family that consumes a request left by the deprecated two-step helpers
-    (bn_next_prepare / bn_next_bwd_prepare / gemm_next_scales) -- consumed or dropped here, like the C-level armed state was."""
-    if want_bn:
-        left = _take("bn")
-        bn = bn if bn is not None else left
-    if want_scales:
-        left = _take("scales")
-        scales = scales if scales is not None else left
+    (want_bn / want_scales: which families of options the call accepts -- documentation at the call sites.)"""
     if bn is None and scales is None and not prepared:
         return None, None
     o = _Opts()
@@ -221,13 +206,6 @@ def _mk_opts(bn=None, scales=None, prepared=False, want_bn=False, want_scales=Fa
         flags |= OPT_PREPARED
     o.flags = flags
     return ctypes.c_void_p(ctypes.addressof(o)), (o, bn, scales)
-
-
-def gemm_next_scales(slot_a, slot_b=None, prime=False):
-    """DEPRECATED two-step form (the engines pass ``scales=`` to the call itself): name the scale slots of the operands of the
-    NEXT gemm_* call of this thread.  Since ABI 3 this is remembered on the HOST side and handed to that call as its explicit
-    per-call option; nothing is armed in the library."""
-    _pending.scales = (slot_a, slot_b, bool(prime))
 
 
 def gemm_scales_roll(slots):
@@ -624,9 +602,8 @@ def gemm_nn(a, w, out=None, n_rows=None, wplanes=None, scales=None):
 
 
 def gemm_nn_bnred_supported(M, K, n_rows, dtype=torch.float32):
-    """Does gemm_nn_bnred exist for a dgrad M -> K over n_rows rows (row-register kernels; bfloat16 features: round 5)?"""
-    if dtype == torch.bfloat16:
-        return bool(_lib.lib().ddmp_gemm_nn_bnred_bf16_supported(int(M), int(K), int(n_rows)))
+    """Does gemm_nn_bnred exist for a dgrad M -> K over n_rows rows (row-register kernel, float32 features; the bfloat16 twin
+    of round 5 measured no gain inside the step and left the library in round 6: experiments/r05/)?"""
     return dtype == torch.float32 and bool(_lib.lib().ddmp_gemm_nn_bnred_supported(int(M), int(K), int(n_rows)))
 
 
@@ -643,17 +620,8 @@ def gemm_nn_bnred(a, w, yp, bn4, sums, out=None, slope=SLOPE, n_rows=None, wplan
         out = torch.empty((n, K), dtype=a.dtype, device=a.device)
     out, ldo = _mat(out, "out", a)
     L = _lib.lib()
-    if a.dtype == torch.bfloat16:
-        nb = (L.ddmp_gemm_rows_ws_bytes(K, M, _dt(a)) + 255) // 256 * 256
-        sb = L.ddmp_gemm_nt_stats_bf16_workspace_bytes(n, K)
-        ws = Workspace.get(nb + sb, a.device)
-        with _timed("gemm_nn", (M, K), 2.0 * n * (2 * K + M) + 4.0 * K * M, 2.0 * n * K * M, survey=2.0 * n * (K + M)):
-            o, keep = _mk_opts(bn, want_bn=True)
-            st = L.ddmp_gemm_nn_bnred_bf16_o(_p(a), lda, _p(w), ldw, _p(out), ldo, n, M, K, _p(yp), ldyp, _p(bn4[0]), _p(bn4[1]),
-                                             _p(bn4[2]), _p(bn4[3]), slope, _p(sums), _p(ws), nb, ws.data_ptr() + nb,
-                                             ws.numel() - nb, _stream(), o)
-        check(st, "ddmp_gemm_nn_bnred_bf16")
-        return out
+    if a.dtype != torch.float32:
+        raise DdmpError("gemm_nn_bnred: float32 features only")
     nb = (L.ddmp_gemm_rows_workspace_bytes(K, M) + 255) // 256 * 256
     sb = L.ddmp_gemm_nt_stats_workspace_bytes(n, K)
     ws = Workspace.get(nb + sb, a.device)
@@ -830,17 +798,6 @@ def bn_prepare(sums, n_total, gamma, beta, out4, running=None, eps=BN_EPS, momen
                                         _p(out4[0]), _p(out4[1]), _p(out4[2]), _p(out4[3]), _p(rm), _p(rv), _stream())
     check(st, "ddmp_bn_prepare_f32")
     return out4
-
-
-def bn_next_prepare(n_total, gamma, beta, out4, running=None, eps=BN_EPS, momentum=BN_MOMENTUM):
-    """DEPRECATED two-step form of ``bn=BnFwd(...)``: remembered on the HOST side for the next statistics-producing call of this
-    thread (bn_stats / gemm_nt_stats / spmm_stats), which receives it as its explicit per-call option."""
-    _pending.bn = BnFwd(n_total, gamma, beta, out4, running, eps, momentum)
-
-
-def bn_next_bwd_prepare(n_total, bn4, dgamma, dbeta, c10):
-    """DEPRECATED two-step form of ``bn=BnBwd(...)`` (bn_bwd_reduce / spmm_bnred / gemm_nn_bnred)."""
-    _pending.bn = BnBwd(n_total, bn4, dgamma, dbeta, c10)
 
 
 def bn_lrelu_apply(y, scale, shift, out=None, slope=SLOPE):

@@ -63,14 +63,6 @@ class FusedTrainer:
         self.use_graph = use_graph
         self.overlap = overlap and self.peng.comm.world_size == 1
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
-        # weight gradients on a further stream beside the dgrad chain: opt-in (DDMP_ASYNC_WGRAD=1), never in the two-stream
-        # graph (hipStreamEndCapture crashes on that topology).  Round 3 measured +0.4-0.8 ms per iteration at 1M faces for it;
-        # with the round-4 wgrad kernel it LOSES 1.6-2.5 ms (profiles/r04_stream_overlap_ab.txt): kept for A/B only.
-        import os
-        # (round 3, one wgrad in flight so that only tail events are waited on: a single-stream capture works and gains
-        # nothing at 13k faces -- 3.13 vs 3.16 ms --, the two-stream capture with a wgrad stream per net still dumps core)
-        self.peng.async_wgrad = self.neng.async_wgrad = (os.environ.get("DDMP_ASYNC_WGRAD") == "1"
-                                                         and not (use_graph and overlap))
         self._graphs = {}       # gate -> torch.cuda.CUDAGraph
         self._warm = False
         self._t_dev = torch.zeros(1, dtype=torch.int32, device=dev)

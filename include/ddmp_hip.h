@@ -27,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define DDMP_OK 0
 #define DDMP_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported width) */
@@ -77,7 +81,6 @@ int ddmp_graph_create_csr_rows_host(int64_t n_rows_all, int64_t n_cols, const in
                                     const float* dinv_host, int64_t row0, int64_t row1, ddmp_graph** out);
 int ddmp_graph_destroy(ddmp_graph* g);
 int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int* max_row_nnz);
-int ddmp_graph_tables(const ddmp_graph* g, const int32_t** rowptr, const int32_t** col, const float** dinv);
 
 /* ------------------------------------------------------------------ aggregation  Y = A_hat . f(X) (+ bias)
  * Replaces GCNConv.propagate (index_select * norm -> scatter_add) and the `+ bias`.
@@ -110,9 +113,6 @@ int ddmp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, f
                      int64_t n_rows, int K, int M, const float* bias,
                      const float* pro_scale, const float* pro_shift, float slope,
                      void* workspace /*nullable*/, size_t workspace_bytes, ddmp_stream stream);
-int ddmp_gemm_nn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy,
-                     int64_t n_rows, int M, int K, void* workspace /*nullable*/, size_t workspace_bytes,
-                     ddmp_stream stream);
 size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
 /* GEMM arithmetic (process-wide; the environment variable DDMP_GEMM_MODE sets the initial value):
  *   6  = bf16x6 split MFMA: every f32 operand is split into three bf16 terms, six bf16 MFMA products accumulated in
@@ -133,11 +133,7 @@ size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
  * events per slot in [3] (-1: the operand was not finite) and clears the flag. */
 int ddmp_set_gemm_mode(int mode);
 int ddmp_get_gemm_mode(void);
-int ddmp_gemm_next_scales(float* slot_a, float* slot_b, int prime);
 int ddmp_gemm_scales_roll(float* slots, int n_slots, ddmp_stream stream);
-int ddmp_gemm_tn_f32(const float* G, int64_t ldg, const float* Z, int64_t ldz, float* dW, int64_t lddw,
-                     int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift,
-                     float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream);
 
 /* ------------------------------------------------------------------ BatchNorm1d (train mode) + LeakyReLU
  * Replace nn.BatchNorm1d(C) in train mode + nn.LeakyReLU() (util/networks.py:31-44,51-62): batch
@@ -157,10 +153,6 @@ int ddmp_bn_prepare_f32(const double* sums /*[2C]*/, double n_total, int C, cons
 int ddmp_bn_lrelu_apply_f32(const float* Y, int64_t ldy, float* Z, int64_t ldz, int64_t n_rows, int C,
                             const float* scale, const float* shift, float slope, ddmp_stream stream);
 /* backward: sums2 = (sum g, sum g*yhat), g = dZ * LeakyReLU'(scale*y+shift), yhat = (y-mean)*rstd */
-int ddmp_bn_bwd_reduce_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t n_rows, int C,
-                           const float* scale, const float* shift, const float* mean, const float* rstd,
-                           float slope, double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes,
-                           ddmp_stream stream);
 /* sums2 -> dgamma, dbeta and the two folded constants of dY = scale*g + c1*y + c0 */
 int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const float* scale, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, float* c1, float* c0,
@@ -170,12 +162,6 @@ int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const fl
  * stage of that reduction ALSO writes what ddmp_bn_prepare_f32 / ddmp_bn_bwd_prepare_f32 would (same arithmetic, bitwise the
  * same values; the sums are still written) -- one launch less per BatchNorm and direction.  C must be the reduction's width.
  * No device work, no stream: the arguments are remembered until that call; ddmp_bn_next_cancel drops them. */
-int ddmp_bn_next_prepare(double n_total, int C, const float* gamma, const float* beta, float eps, float momentum,
-                         float* scale, float* shift, float* mean, float* rstd, float* running_mean /*nullable*/,
-                         float* running_var /*nullable*/);
-int ddmp_bn_next_bwd_prepare(double n_total, int C, const float* scale, const float* mean, const float* rstd,
-                             float* dgamma, float* dbeta, float* c1, float* c0);
-int ddmp_bn_next_cancel(void);
 /* Everything "armed for the next call" on this host thread -- ddmp_bn_next_* (bit 0), ddmp_gemm_next_scales (bit 1),
  * ddmp_gemm_next_prepared (bit 2) -- as a bit mask, and a cancel for all of it.  Rules of the armed state (ABI 2): it is
  * consumed or DROPPED by the next entry point of its family whether that call succeeds or returns an error; a BatchNorm
@@ -184,13 +170,8 @@ int ddmp_bn_next_cancel(void);
  * DEPRECATED since ABI 3: the *_o entry points at the end of this header take the same requests as an explicit per-call
  * ddmp_opts argument; dual-dmp_amd/engine.py no longer arms anything. */
 int ddmp_next_pending(void);
-int ddmp_next_cancel(void);
 /* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias; dbias_sums NULL: dY only -- behind
  * a BatchNorm those sums are zero in exact arithmetic) */
-int ddmp_bn_bwd_apply_f32(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, float* dY, int64_t lddy,
-                          int64_t n_rows, int C, const float* scale, const float* shift, const float* c1,
-                          const float* c0, float slope, double* dbias_sums /*[C]*/, void* workspace,
-                          size_t workspace_bytes, ddmp_stream stream);
 int ddmp_colsum_f32(const float* X, int64_t ldx, int64_t n_rows, int C, double* sums /*[C]*/, void* workspace,
                     size_t workspace_bytes, ddmp_stream stream);
 int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_stream stream);
@@ -202,14 +183,7 @@ int ddmp_f64_to_f32(const double* in, float* out, int64_t n, ddmp_stream stream)
  * b1 [16], W2 [3,16], b2 [3]; out / dout [n,3] contiguous.  Backward writes dZ [n,32] (gradient w.r.t.
  * the activated conv12 features) and overwrites the four parameter gradients.
  */
-int ddmp_head_fwd_f32(const float* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
-                      float slope, const float* W1, const float* b1, const float* W2, const float* b2,
-                      int kind, const float* x_pos /*kind 0*/, float* out, ddmp_stream stream);
 size_t ddmp_head_bwd_workspace_bytes(int64_t n_rows);
-int ddmp_head_bwd_f32(const float* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
-                      float slope, const float* W1, const float* b1, const float* W2, const float* b2,
-                      int kind, const float* dout, float* dZ, int64_t lddz, float* dW1, float* db1,
-                      float* dW2, float* db2, void* workspace, size_t workspace_bytes, ddmp_stream stream);
 
 /* ------------------------------------------------------------------ losses (util/loss.py)
  * Index tables are int32 device arrays: faces [F,3], f2f [F,3] (-1 padded, symmetric on valid entries),
@@ -284,11 +258,6 @@ int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, 
  * backward: also returns that layer's column reductions sums2 = ddmp_bn_bwd_reduce_f32(Y, Yp, scale, shift, mean,
  * rstd) from the kernel's epilogue (float32 partials per 64-row chunk, summed in float64); other widths run the two
  * calls one after the other. */
-size_t ddmp_spmm_bnred_workspace_bytes(int64_t n_rows, int C);
-int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
-                        const float* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
-                        const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace,
-                        size_t workspace_bytes, ddmp_stream stream);
 /* GCNConv.propagate of a transform-first layer (forward) that also returns the BatchNorm statistics of its output
  * (float64 [2C]: column sums of Y and of Y^2 = ddmp_bn_stats_f32(Y)) from the gather kernel's epilogue (round 3).  `ref`
  * [C]: a per-column reference near the column means (the caller's previous batch means; zeros are valid): the kernel
@@ -301,10 +270,6 @@ int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float*
                         const float* bias /*nullable*/, const float* pro_scale /*nullable*/,
                         const float* pro_shift /*nullable*/, float slope, const float* ref /*[C], nullable*/,
                         double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
-int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
-                         const float* bias /*nullable*/, const float* pro_scale /*nullable*/,
-                         const float* pro_shift /*nullable*/, float slope, const float* ref /*[C], nullable*/,
-                         double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes, ddmp_stream stream);
 /* dtype-tagged form; workspace >= max(ddmp_spmm_bnred_ws_bytes, ddmp_colreduce_workspace_bytes) */
 int ddmp_spmm_stats(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype,
                     const float* bias, const float* pro_scale, const float* pro_shift, float slope, const float* ref,
@@ -350,7 +315,6 @@ int ddmp_gemm_nt_stats_f32(const float* A, int64_t lda, const float* W, int64_t 
 int ddmp_gemm_prepare_weights(int n, const float* const* W, const int64_t* ldw, const int* M, const int* K, const int* form,
                               const int* has_pro /*nullable*/, void* const* planes, const size_t* planes_bytes,
                               int64_t n_rows, float* scratch, ddmp_stream stream);
-int ddmp_gemm_next_prepared(void);
 /* the owner of a plane buffer is about to free it: drop what this thread recorded for it (NULL: everything) */
 int ddmp_gemm_forget_planes(const void* planes);
 int ddmp_gemm_tn_bnbwd_supported(int cout, int cin, int64_t n_rows);   /* the fused wgrad alone (a first layer has no dgrad) */
@@ -407,28 +371,8 @@ int ddmp_mad_f64(int64_t F, const float* n1 /*[F,3] f32*/, const double* n2 /*[F
 #define DDMP_F32 0
 #define DDMP_BF16 1
 
-int ddmp_spmm_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
-                   const float* bias, const float* pro_scale, const float* pro_shift, float slope, ddmp_stream stream);
-size_t ddmp_spmm_bnred_bf16_workspace_bytes(int64_t n_rows, int C);
-int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int64_t ldx, uint16_t* Y, int64_t ldy, int C,
-                         const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift, const float* mean,
-                         const float* rstd, float slope, double* sums2 /*[2C]*/, void* workspace, size_t workspace_bytes,
-                         ddmp_stream stream);
-int ddmp_spmm_bnbwd_bf16(const ddmp_graph* g, const uint16_t* dZ, int64_t lddz, const uint16_t* Yb, int64_t ldyb,
-                         uint16_t* out, int64_t ld_out, int C, const float* a, const float* b, const float* c1,
-                         const float* c0, float slope, ddmp_stream stream);
 /* nt / nn: K resp. M (the contraction) a multiple of 32 (nt also K = 8 | 16, the first layer), outputs <= 512 columns;
  * workspace >= ddmp_gemm_rows_bf16_workspace_bytes(K, M) holds the bf16 weight planes */
-size_t ddmp_gemm_rows_bf16_workspace_bytes(int K, int M);
-int ddmp_gemm_nt_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
-                      int64_t n_rows, int K, int M, const float* bias, const float* pro_scale, const float* pro_shift,
-                      float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream);
-int ddmp_gemm_nn_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
-                      int64_t n_rows, int M, int K, void* workspace, size_t workspace_bytes, ddmp_stream stream);
-size_t ddmp_gemm_tn_bf16_workspace_bytes(int64_t n_rows, int M, int K);
-int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t ldz, float* dW, int64_t lddw,
-                      int64_t n_rows, int M, int K, const float* pro_scale, const float* pro_shift, float slope,
-                      void* workspace, size_t workspace_bytes, ddmp_stream stream);
 /* Fused forms on the row-register kernel (csrc/gemm_rr_b16.inc; round 3): the streaming BatchNorm passes of the bf16 step
  * folded into the GEMMs, as the *_f32 namesakes do for float32 features.
  *   ddmp_gemm_fused_bf16_supported  bit 0: ddmp_gemm_nt_stats_bf16, bit 1: the two *_bnbwd_bf16 forms exist AND pay for a
@@ -439,19 +383,7 @@ int ddmp_gemm_tn_bf16(const uint16_t* G, int64_t ldg, const uint16_t* Z, int64_t
  *                                   load: what ddmp_bn_bwd_apply_bf16 would have written, never stored
  *   ddmp_gemm_tn_bnbwd_bf16         dW[M,K] = dY^T . f(Z), the same dY (reference op: GCNConv.lin backward behind
  *                                   BatchNorm1d + LeakyReLU, util/networks.py:31-44,51-62)
- *   ddmp_gemm_nn_bnred_bf16         (round 5; the bf16 twin of ddmp_gemm_nn_bnred_f32) out[n,K] = bf16(A[n,M] . W[M,K]) AND
- *                                   sums2[2K] = ddmp_bn_bwd_reduce_bf16(out, Yp, ...) of the output AS STORED, from the epilogue
- *                                   (one read of Yp instead of a pass over out and Yp); workspace >=
- *                                   ddmp_gemm_rows_bf16_workspace_bytes(M, K), stats_ws >= ddmp_gemm_nt_stats_bf16_workspace_bytes
- *                                   (n_rows, K); DDMP_EINVAL for shapes the row-register kernel does not take.  ..._supported:
- *                                   the shapes an engine should route here -- none by default, the form measured no gain inside
- *                                   the step (csrc/gemm_b16.hip); DDMP_BF16_GEMM_BNRED=1 for A/B */
-int ddmp_gemm_nn_bnred_bf16_supported(int M, int K, int64_t n_rows);
-int ddmp_gemm_nn_bnred_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out,
-                            int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale,
-                            const float* shift, const float* mean, const float* rstd, float slope, double* sums2,
-                            void* workspace, size_t workspace_bytes, void* stats_ws, size_t stats_ws_bytes,
-                            ddmp_stream stream);
+ *   (round 5's ddmp_gemm_nn_bnred_bf16 -- measured no gain inside the step -- left the library in round 6: experiments/r05/) */
 int ddmp_gemm_fused_bf16_supported(int cout, int cin, int64_t n_rows);
 size_t ddmp_gemm_nt_stats_bf16_workspace_bytes(int64_t n_rows, int M);
 int ddmp_gemm_nt_stats_bf16(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* Y, int64_t ldy,
@@ -479,13 +411,6 @@ int ddmp_bn_bwd_apply_bf16(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, 
                            int64_t n_rows, int C, const float* scale, const float* shift, const float* c1,
                            const float* c0, float slope, double* dbias_sums /*[C]*/, void* workspace,
                            size_t workspace_bytes, ddmp_stream stream);
-int ddmp_head_fwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
-                       float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
-                       const float* x_pos /*kind 0*/, float* out, ddmp_stream stream);
-int ddmp_head_bwd_bf16(const uint16_t* Y, int64_t ldy, int64_t n_rows, const float* scale, const float* shift,
-                       float slope, const float* W1, const float* b1, const float* W2, const float* b2, int kind,
-                       const float* dout, uint16_t* dZ, int64_t lddz, float* dW1, float* db1, float* dW2, float* db2,
-                       void* workspace, size_t workspace_bytes, ddmp_stream stream);
 /* Multi-device halo packing (the reference is single-device, main.py:51): dst[r,:] = src[idx[r],:]
  * (scatter = 0: the boundary rows a rank sends, in the order of its halo plan) or dst[idx[r],:] = src[r,:] (scatter = 1);
  * idx int64 on the device; rows of C elements with C * element size a multiple of 16 bytes. */
@@ -527,7 +452,6 @@ int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_st
  * 128-byte slab at a time (row_bytes a multiple of 128): the ceiling of that pattern, whatever the graph */
 int ddmp_copy_probe_rows(const void* src, void* dst, int64_t n_rows, int row_bytes, ddmp_stream stream);
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
-int ddmp_bf16_to_f32(const uint16_t* in, float* out, int64_t n, ddmp_stream stream);
 
 /* dtype-tagged forms (dtype = DDMP_F32 | DDMP_BF16): what a binding of the reference's GCNConv / BatchNorm1d / Linear
  * call sites (util/networks.py:15-26,31-44,51-67) uses when the feature dtype is a run-time choice */
@@ -628,10 +552,6 @@ int ddmp_gemm_nn_bnred_f32_o(const float* A, int64_t lda, const float* W, int64_
     int64_t n_rows, int M, int K, const float* Yp, int64_t ldyp, const float* scale, const float* shift,
     const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
     void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts);
-int ddmp_gemm_nn_bnred_bf16_o(const uint16_t* A, int64_t lda, const float* W, int64_t ldw, uint16_t* out, int64_t ld_out,
-    int64_t n_rows, int M, int K, const uint16_t* Yp, int64_t ldyp, const float* scale, const float* shift,
-    const float* mean, const float* rstd, float slope, double* sums2, void* workspace, size_t workspace_bytes,
-    void* stats_ws, size_t stats_ws_bytes, ddmp_stream stream, const ddmp_opts* opts);
 int ddmp_gemm_nn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int64_t ldyb, const float* W, int64_t ldw,
     float* out, int64_t ld_out, int64_t n_rows, int M, int K, const float* a, const float* b, const float* c1,
     const float* c0, float slope, void* workspace, size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
@@ -640,6 +560,9 @@ int ddmp_gemm_tn_bnbwd_f32_o(const float* dZ, int64_t lddz, const float* Yb, int
     const float* c0, const float* pro_scale , const float* pro_shift , float slope, void* workspace,
     size_t workspace_bytes, ddmp_stream stream, const ddmp_opts* opts);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -22,57 +22,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, 0, None) == -1
     assert lib.ddmp_gemm_tn_workspace_bytes(1000000, 512, 512) > 0
     # round 3 entry points: argument checks need no device either
-    assert lib.ddmp_bn_next_prepare(0.0, 32, None, None, 1e-5, 0.1, None, None, None, None, None, None) == -1
-    assert lib.ddmp_bn_next_bwd_prepare(10.0, 0, None, None, None, None, None, None, None) == -1
-    assert lib.ddmp_bn_next_cancel() == 0
     assert lib.ddmp_gemm_prepare_weights(25, None, None, None, None, None, None, None, None, 1000, None, None) == -1   # > 24 matrices
-    assert lib.ddmp_gemm_next_prepared() == 0
     assert lib.ddmp_spmm_stats_supported(256) == 1 and lib.ddmp_spmm_stats_supported(40) == 0
 
 
-def test_armed_state_cannot_leak_past_an_error():
-    """ABI 2 (include/ddmp_hip.h): what ddmp_bn_next_* / ddmp_gemm_next_scales / ddmp_gemm_next_prepared arm for "the next call"
-    is consumed OR dropped by the next entry point of its family even when that call fails its argument checks, is never
-    attached to a reduction of another width, and is cancelled by the host mirror's error path -- an error or an exception
-    between "arm" and "call" cannot hand coefficients / scale slots to a later, unrelated launch.  No device work involved."""
-    from dual_dmp_amd import _lib
-    lib = _lib.lib()
-    buf = (ctypes.c_float * 64)()
-    p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.ddmp_next_cancel() == 0 and lib.ddmp_next_pending() == 0
-    # BatchNorm coefficients armed, then the armed call fails: dropped, not left for the next reduction
-    assert lib.ddmp_bn_next_prepare(100.0, 32, p, p, 1e-5, 0.1, p, p, p, p, None, None) == 0
-    assert lib.ddmp_next_pending() == 1
-    assert lib.ddmp_bn_stats_f32(None, 0, 0, 32, None, None, 0, None) == -1
-    assert lib.ddmp_next_pending() == 0
-    # armed for 32 columns, the next reduction has 64 (the armed call was never made): dropped, even though it has a sums buffer
-    assert lib.ddmp_bn_next_bwd_prepare(100.0, 32, p, p, p, p, p, p, p) == 0
-    sums = (ctypes.c_double * 128)()
-    assert lib.ddmp_bn_stats_f32(None, 0, 0, 64, ctypes.cast(sums, ctypes.c_void_p), None, 0, None) == -1
-    assert lib.ddmp_next_pending() == 0
-    # scale slots + prepared planes: consumed at the top of a GEMM entry that then fails
-    assert lib.ddmp_gemm_next_scales(p, p, 0) == 0 and lib.ddmp_gemm_next_prepared() == 0
-    assert lib.ddmp_next_pending() == 6
-    assert lib.ddmp_gemm_nt_f32(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, 0, None) == -1
-    assert lib.ddmp_next_pending() == 0
-    # a failing call of ANOTHER family leaves the GEMM state armed at the C level; the host mirror's error path cancels it
-    assert lib.ddmp_gemm_next_scales(p, None, 1) == 0
-    assert lib.ddmp_bn_next_prepare(100.0, 32, p, p, 1e-5, 0.1, p, p, p, p, None, None) == 0
-    with pytest.raises(_lib.DdmpError):
-        _lib.check(lib.ddmp_spmm_f32(None, None, 0, None, 0, 0, None, None, None, 0.01, None), "ddmp_spmm_f32")
-    assert lib.ddmp_next_pending() == 0
-    assert lib.ddmp_gemm_forget_planes(None) == 0 and lib.ddmp_gemm_forget_planes(p) == 0
-
-
 def test_per_call_options_reach_their_own_call_only():
-    """ABI 3: the *_o entry points take what used to be armed "for the next call" as an explicit ddmp_opts argument.  The
-    options apply to that call alone -- whatever it returns --, nothing armed earlier (deprecated ddmp_*_next_* calls) can reach
-    an _o call, and a malformed block is an argument error.  No device work involved (every call fails its argument checks)."""
+    """ABI 3: the *_o entry points take what ABI 2 armed "for the next call" as an explicit ddmp_opts argument (the arming calls
+    themselves are gone from the ABI since round 6).  The options apply to that call alone -- whatever it returns -- and a
+    malformed block is an argument error.  No device work involved (every call fails its argument checks)."""
     from dual_dmp_amd import _lib, ops
     lib = _lib.lib()
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p)
-    assert lib.ddmp_next_cancel() == 0
+    assert lib.ddmp_next_pending() == 0
+    for gone in ("ddmp_bn_next_prepare", "ddmp_bn_next_bwd_prepare", "ddmp_gemm_next_scales", "ddmp_gemm_next_prepared", "ddmp_next_cancel"):
+        assert not hasattr(lib, gone), gone                      # (hidden visibility: not exported any more)
 
     class T:                                                     # a stand-in with .data_ptr() / .numel()
         def data_ptr(self):
@@ -86,9 +50,7 @@ def test_per_call_options_reach_their_own_call_only():
     # the wrapped call fails its argument checks: the options are gone afterwards
     assert lib.ddmp_gemm_nt_stats_f32_o(None, 0, None, 0, None, 0, 0, 0, 0, None, None, None, 0.01, None, None, 0, None, 0, None, o) == -1
     assert lib.ddmp_next_pending() == 0
-    # state armed through the deprecated calls does not reach an _o call (and is gone after it)
-    assert lib.ddmp_gemm_next_scales(p, p, 0) == 0 and lib.ddmp_next_pending() == 2
-    assert lib.ddmp_gemm_nn_o(None, 0, None, 0, None, 0, 0, 0, 0, 0, None, 0, None, None) == -1
+    assert lib.ddmp_gemm_nn_o(None, 0, None, 0, None, 0, 0, 0, 0, 0, None, 0, None, o) == -1
     assert lib.ddmp_next_pending() == 0
     # a block of another size / with unknown flags / with both BatchNorm directions: argument error before the call
     keep[0].struct_size = 8

@@ -260,51 +260,6 @@ def test_gemm_bnbwd_bf16_fused_matches_composition(dev, n, cin, cout, monkeypatc
     assert relerr(dw, ops.gemm_tn(dy, pg)) < 2e-6                                   # same operands, same arithmetic
 
 
-@pytest.mark.parametrize("n,M,K", [(66000, 256, 512), (70001, 128, 256), (33000, 64, 128), (40001, 512, 256), (20000, 256, 128)])
-def test_gemm_nn_bnred_bf16_matches_the_separate_pass(dev, n, M, K):
-    """Round 5: the transform-first dgrad on bf16 features with the NEXT BatchNorm-backward reductions in its epilogue
-    (ddmp_gemm_nn_bnred_bf16, row-register kernel).  The output is the bf16 product; the sums are those of the STORED output:
-    == ddmp_bn_bwd_reduce_bf16 on what the call wrote (float32 partial sums over 16 rows, float64 from there on), and -- with
-    the per-call options -- the coefficients that the stand-alone prepare kernel derives from them."""
-    from dual_dmp_amd import ops
-    if os.environ.get("DDMP_GEMM_RR") == "0":
-        pytest.skip("row-register kernels disabled")
-    # (the engine dispatches what ops.gemm_nn_bnred_supported names -- nothing by default, the form did not pay inside the step;
-    #  the entry point takes every shape the row-register kernel takes)
-    torch.manual_seed(n + M + K)
-    ab, a = rb(torch.randn(n, M) * 0.7)
-    ypb, yp = rb(torch.randn(n, K) * 2 + 0.3)
-    w = torch.randn(M, K) / M ** 0.5
-    wq = w.to(BF).double()
-    bn4 = torch.stack([torch.rand(K) + 0.5, torch.randn(K), torch.randn(K) * 0.3, torch.rand(K) + 0.5])
-    ag, ypg, wg, bn4g = ab.to(dev), ypb.to(dev), w.to(dev), bn4.to(dev)
-    sums = torch.zeros(2 * K, dtype=torch.float64, device=dev)
-    out = ops.gemm_nn_bnred(ag, wg, ypg, bn4g, sums)
-    assert out.dtype == BF and out.shape == (n, K)
-    atol = 3e-6 * float((a.abs() @ wq.abs()).max())
-    nbad, worst = close_bf16(out, a @ wq, atol)
-    assert nbad == 0, worst
-    ref = torch.zeros_like(sums)
-    ops.bn_bwd_reduce(out, ypg, bn4g, sums2=ref)
-    scale = float(ref.abs().max())
-    assert float((sums - ref).abs().max()) <= 2e-6 * scale, (float((sums - ref).abs().max()), scale)
-    # float64 formula on the stored output
-    od = out.double().cpu()
-    g = od * torch.where(yp * bn4[0].double() + bn4[1].double() > 0, 1.0, ops.SLOPE)
-    yhat = (yp - bn4[2].double()) * bn4[3].double()
-    assert relerr(sums[:K], g.sum(0)) < 2e-5 and relerr(sums[K:], (g * yhat).sum(0)) < 2e-5
-    # the coefficients from the call's own second stage == the stand-alone kernel on the call's sums
-    dg, db, c10 = torch.empty(K, device=dev), torch.empty(K, device=dev), torch.empty(2, K, device=dev)
-    out2 = ops.gemm_nn_bnred(ag, wg, ypg, bn4g, sums, bn=ops.BnBwd(float(n), bn4g, dg, db, c10))
-    assert torch.equal(out2, out)
-    dg2, db2, c102 = torch.empty_like(dg), torch.empty_like(db), torch.empty_like(c10)
-    ops.bn_bwd_prepare(sums, float(n), bn4g, dg2, db2, c102)
-    assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(c10, c102)
-    for _ in range(2):                                                              # stable from launch to launch
-        s2 = torch.zeros_like(sums)
-        assert torch.equal(ops.gemm_nn_bnred(ag, wg, ypg, bn4g, s2), out) and torch.equal(s2, sums)
-
-
 @pytest.mark.parametrize("n,M,K", [(1000, 64, 32), (3000, 512, 512), (2049, 512, 256), (2500, 256, 512), (900, 32, 64),
                                     (1300, 128, 256), (130, 256, 256), (66000, 512, 256), (33001, 256, 512), (20500, 128, 128)])
 def test_gemm_nn_bf16(dev, n, M, K):

@@ -139,7 +139,7 @@ def test_interior_boundary_split_is_bit_identical_with_and_without_overlap(P, mo
     reference no halo row (the leading chunks of the interior-first local order) while the layer's halo exchange travels, the
     boundary rows behind it (GcnEngine ``split``; row-slice graphs of ddmp_graph_create_csr_rows_host).  48,400 faces over P
     threaded ranks, gate open, bnfloop 2, two iterations:
-      * split + overlap (default) vs the same two launches with every exchange waited for first (DDMP_DIST_OVERLAP=0): bit-identical
+      * split + overlap (default) vs the same two launches with every exchange waited for first (DDMP_DIST_SPLIT=noverlap): bit-identical
         losses, outputs and parameters;
       * vs the unsplit partitioned path (DDMP_DIST_SPLIT=0: one launch per aggregation): equal to float32 rounding -- the fused
         column sums of the two halves are added in float64, another association of the same terms;
@@ -154,8 +154,7 @@ def test_interior_boundary_split_is_bit_identical_with_and_without_overlap(P, mo
     data = dataset_from_meshes(noisy, smooth)
 
     def run(env):
-        for k in ("DDMP_DIST_SPLIT", "DDMP_DIST_OVERLAP"):
-            monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv("DDMP_DIST_SPLIT", raising=False)
         for k, val in env.items():
             monkeypatch.setenv(k, val)
         nets = []
@@ -182,7 +181,7 @@ def test_interior_boundary_split_is_bit_identical_with_and_without_overlap(P, mo
         assert not errs, errs
         return results
 
-    a, b, c = run({}), run({"DDMP_DIST_OVERLAP": "0"}), run({"DDMP_DIST_SPLIT": "0"})
+    a, b, c = run({}), run({"DDMP_DIST_SPLIT": "noverlap"}), run({"DDMP_DIST_SPLIT": "0"})
     for r in range(P):
         assert a[r][3] == (True, True) and b[r][3] == (True, True) and c[r][3] == (False, False), (r, a[r][3], c[r][3])
         assert 0 < a[r][4][0] < a[r][4][1]

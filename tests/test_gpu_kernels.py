@@ -104,7 +104,7 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         g = ops.graph_for(ei.to(dev), n)
         sel = L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1       # (144,400 faces / 72,200 vertices: both from 64k rows)
         assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
-        if os.environ.get("DDMP_SPMM_PATCH") is None and os.environ.get("DDMP_SPMM_PATCH_FORMS") is None:
+        if os.environ.get("DDMP_SPMM_PATCH") is None:
             # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256
             assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
             assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0
@@ -181,8 +181,8 @@ def test_spmm_with_forward_statistics(dev, graphs, C, dtype):
         # with the tail-fused coefficients on top
         bn4, run = torch.zeros(4, C, device=dev), torch.stack([torch.zeros(C), torch.ones(C)]).to(dev)
         gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
-        ops.bn_next_prepare(n, gamma, beta, bn4, running=(run[0], run[1]))
-        ops.spmm_stats(g, x, out, (mean * 1.01).contiguous(), sums, bias=bias)
+        ops.spmm_stats(g, x, out, (mean * 1.01).contiguous(), sums, bias=bias,
+                       bn=ops.BnFwd(n, gamma, beta, bn4, running=(run[0], run[1])))
         want = torch.zeros(4, C, device=dev)
         ops.bn_prepare(sums, n, gamma, beta, want)
         assert torch.equal(bn4, want)
@@ -508,11 +508,9 @@ def test_f16x3_per_row_and_per_column_error(dev, f16x3):
     slots = torch.zeros(1, 4, device=dev)
     for target, stale in ((15, False), (10, True)):
         if stale:
-            ops.gemm_next_scales(slots[0], None, prime=True)
-            ops.gemm_nt(ag, wg)
+            ops.gemm_nt(ag, wg, scales=(slots[0], None, True))
             ops.gemm_scales_roll(slots)
-            ops.gemm_next_scales(slots[0], None)
-        y = ops.gemm_nt(ag, wg).double().cpu()
+        y = ops.gemm_nt(ag, wg, **({"scales": (slots[0], None, False)} if stale else {})).double().cpu()
         err = (y - ref).abs()
         bound = 2.0 * _f16x3_elementwise_bound(a, w, target) + 1e-300
         worst = float((err / bound).max())
@@ -547,33 +545,27 @@ def test_f16x3_scale_slots(dev, f16x3):
     ag, wg, gg = a.to(dev), w.to(dev), g.to(dev)
     slots = torch.zeros(2, 4, device=dev)
     ref = a.double() @ w.double().t()
-    ops.gemm_next_scales(slots[0], None, prime=True)
-    assert relerr(ops.gemm_nt(ag, wg), ref) < 2e-6
+    assert relerr(ops.gemm_nt(ag, wg, scales=(slots[0], None, True)), ref) < 2e-6
     amax = float(a.abs().max())
     assert float(slots[0, 0]) == amax and float(slots[0, 1]) == amax          # measured, and seen by the kernel
     ops.gemm_scales_roll(slots)
     assert float(slots[0, 0]) == amax and float(slots[0, 1]) == 0.0
     for grow in (1.0, 30.0, 0.01):                                  # stale scale, data moved: still float32-class
-        ops.gemm_next_scales(slots[0], None)
-        assert relerr(ops.gemm_nt(ag * grow, wg), ref * grow) < 2e-6
+        assert relerr(ops.gemm_nt(ag * grow, wg, scales=(slots[0], None, False)), ref * grow) < 2e-6
         assert int(slots[0, 2].view(torch.int32)) == 0
         assert float(slots[0, 1]) == float((a * grow).abs().max())
         slots[0, 1] = 0.0
     # both operands of the wgrad form
-    ops.gemm_next_scales(slots[1], slots[0], prime=True)
-    assert relerr(ops.gemm_tn(gg, ag), g.double().t() @ a.double()) < 3e-6
+    assert relerr(ops.gemm_tn(gg, ag, scales=(slots[1], slots[0], True)), g.double().t() @ a.double()) < 3e-6
     ops.gemm_scales_roll(slots)
-    ops.gemm_next_scales(slots[1], slots[0])
-    assert relerr(ops.gemm_tn(gg * 5, ag), 5 * (g.double().t() @ a.double())) < 3e-6
+    assert relerr(ops.gemm_tn(gg * 5, ag, scales=(slots[1], slots[0], False)), 5 * (g.double().t() @ a.double())) < 3e-6
     assert int(slots[:, 2].view(torch.int32).abs().sum()) == 0
     # beyond the head-room (x 1000 between two iterations): flagged, healed, counted
     ops.gemm_scales_roll(slots)
-    ops.gemm_next_scales(slots[0], None)
-    y = ops.gemm_nt(ag * 1000.0, wg)
+    y = ops.gemm_nt(ag * 1000.0, wg, scales=(slots[0], None, False))
     assert int(slots[0, 2].view(torch.int32)) == 1
     assert relerr(y, ref * 1000.0) < 2e-6                          # NOT the clamped product
-    ops.gemm_next_scales(slots[1], slots[0])                        # the wgrad on the same (outgrown) operand slot
-    dw = ops.gemm_tn(gg, ag * 1000.0)
+    dw = ops.gemm_tn(gg, ag * 1000.0, scales=(slots[1], slots[0], False))      # the wgrad on the same (outgrown) operand slot
     assert relerr(dw, 1000.0 * (g.double().t() @ a.double())) < 3e-6
     ops.gemm_scales_roll(slots)
     assert int(slots[0, 2].view(torch.int32)) == 0 and float(slots[0, 3]) == 1.0 and float(slots[1, 3]) == 0.0
@@ -584,24 +576,20 @@ def test_f16x3_scale_slots(dev, f16x3):
     c10 = torch.stack([torch.randn(M) * 0.1, torch.randn(M) * 0.1]).to(dev)
     if ops.gemm_bnbwd_supported(M, K, n):
         slot = torch.zeros(1, 4, device=dev)
-        ops.gemm_next_scales(slot[0], None, prime=True)
-        ops.gemm_nn_bnbwd(gg, yb, wg, bn4, c10)
+        ops.gemm_nn_bnbwd(gg, yb, wg, bn4, c10, scales=(slot[0], None, True))
         ops.gemm_scales_roll(slot)
-        ops.gemm_next_scales(slot[0], None)
-        big = ops.gemm_nn_bnbwd(gg * 1e6, yb * 1e3, wg, bn4, c10)
+        big = ops.gemm_nn_bnbwd(gg * 1e6, yb * 1e3, wg, bn4, c10, scales=(slot[0], None, False))
         dy = torch.empty(n, M, device=dev)
         ops.bn_bwd_apply(gg * 1e6, yb * 1e3, bn4, c10, dy, torch.empty(2 * M, dtype=torch.float64, device=dev))
         assert int(slot[0, 2].view(torch.int32)) == 1
         assert relerr(big, dy.double().cpu() @ w.double()) < 3e-6
     # a non-finite operand cannot be healed: the roll marks the slot -1
     slot = torch.zeros(1, 4, device=dev)
-    ops.gemm_next_scales(slot[0], None, prime=True)
-    ops.gemm_nt(ag, wg)
+    ops.gemm_nt(ag, wg, scales=(slot[0], None, True))
     ops.gemm_scales_roll(slot)
     bad = ag.clone()
     bad[5, 7] = float("inf")
-    ops.gemm_next_scales(slot[0], None)
-    ops.gemm_nt(bad, wg)
+    ops.gemm_nt(bad, wg, scales=(slot[0], None, False))
     ops.gemm_scales_roll(slot)
     assert float(slot[0, 3]) == -1.0
 
@@ -657,9 +645,9 @@ def test_batchnorm_lrelu_forward_backward(dev, n, C):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("n,C", [(1500, 32), (13068, 512), (70001, 256)])
 def test_tail_fused_coefficients_are_bitwise_those_of_the_prepare_kernels(dev, graphs, n, C, dtype):
-    """ddmp_bn_next_prepare / ddmp_bn_next_bwd_prepare: the second stage of the armed reduction writes the BatchNorm
-    coefficients itself (finalize.h) -- same sums, same coefficients, same running statistics, on every reducing entry;
-    an armed call whose route has no second stage launches the stand-alone kernel by itself."""
+    """The per-call option ``bn=`` (DDMP_OPT_BN_FWD / DDMP_OPT_BN_BWD of the ``_o`` entry points): the second stage of the call's
+    reduction writes the BatchNorm coefficients itself (finalize.h) -- same sums, same coefficients, same running statistics, on
+    every reducing entry; a call whose route has no second stage launches the stand-alone kernel by itself."""
     from dual_dmp_amd import ops
     torch.manual_seed(n + C)
     y = (torch.randn(n, C, device=dev) * 2 + 1).to(dtype)
@@ -669,15 +657,13 @@ def test_tail_fused_coefficients_are_bitwise_those_of_the_prepare_kernels(dev, g
     def coeffs(armed, stats):
         bn4 = torch.zeros(4, C, device=dev)
         run = torch.stack([torch.full((C,), 0.25), torch.full((C,), 2.0)]).to(dev)
-        if armed:
-            ops.bn_next_prepare(n, gamma, beta, bn4, running=(run[0], run[1]))
-        sums = stats()
+        sums = stats({"bn": ops.BnFwd(n, gamma, beta, bn4, running=(run[0], run[1]))} if armed else {})
         if not armed:
             ops.bn_prepare(sums, n, gamma, beta, bn4, running=(run[0], run[1]))
         return sums.clone(), bn4, run
 
-    ref = coeffs(False, lambda: ops.bn_stats(y))
-    got = coeffs(True, lambda: ops.bn_stats(y))
+    ref = coeffs(False, lambda kw: ops.bn_stats(y, **kw))
+    got = coeffs(True, lambda kw: ops.bn_stats(y, **kw))
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
     bn4 = ref[1]
@@ -687,36 +673,30 @@ def test_tail_fused_coefficients_are_bitwise_those_of_the_prepare_kernels(dev, g
         w_ = torch.randn(C, K, device=dev) / 8
         out = torch.empty(n, C, device=dev, dtype=dtype)
         sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
-        r2 = coeffs(False, lambda: (ops.gemm_nt_stats(a_, w_, sums, out=out), sums)[1])
-        g2 = coeffs(True, lambda: (ops.gemm_nt_stats(a_, w_, sums, out=out), sums)[1])
+        r2 = coeffs(False, lambda kw: (ops.gemm_nt_stats(a_, w_, sums, out=out, **kw), sums)[1])
+        g2 = coeffs(True, lambda kw: (ops.gemm_nt_stats(a_, w_, sums, out=out, **kw), sums)[1])
         for a, b in zip(r2, g2):
             assert torch.equal(a, b)
 
     def bwd(armed, red):
         dgamma, dbeta, c10 = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2, C, device=dev)
-        if armed:
-            ops.bn_next_bwd_prepare(n, bn4, dgamma, dbeta, c10)
-        sums2 = red()
+        sums2 = red({"bn": ops.BnBwd(n, bn4, dgamma, dbeta, c10)} if armed else {})
         if not armed:
             ops.bn_bwd_prepare(sums2, n, bn4, dgamma, dbeta, c10)
         return sums2.clone(), dgamma, dbeta, c10
 
-    for a, b in zip(bwd(False, lambda: ops.bn_bwd_reduce(dz, y, bn4)), bwd(True, lambda: ops.bn_bwd_reduce(dz, y, bn4))):
+    for a, b in zip(bwd(False, lambda kw: ops.bn_bwd_reduce(dz, y, bn4, **kw)), bwd(True, lambda kw: ops.bn_bwd_reduce(dz, y, bn4, **kw))):
         assert torch.equal(a, b)
     if n == 1500:                                             # the reductions from the gather's epilogue
         ei, ng = graphs["ico3_f"]
         g = ops.graph_for(ei.to(dev), ng)
         x, yp, o = dz[:ng].contiguous(), y[:ng].contiguous(), torch.empty(ng, C, device=dev, dtype=dtype)
         s2 = torch.empty(2 * C, dtype=torch.float64, device=dev)
-        for a, b in zip(bwd(False, lambda: (ops.spmm_bnred(g, x, o, yp, bn4, s2), s2)[1]),
-                        bwd(True, lambda: (ops.spmm_bnred(g, x, o, yp, bn4, s2), s2)[1])):
+        for a, b in zip(bwd(False, lambda kw: (ops.spmm_bnred(g, x, o, yp, bn4, s2, **kw), s2)[1]),
+                        bwd(True, lambda kw: (ops.spmm_bnred(g, x, o, yp, bn4, s2, **kw), s2)[1])):
             assert torch.equal(a, b)
-    # a non-reducing call in between leaves the request armed for the reduction that follows
-    dgamma, dbeta, c10 = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(2, C, device=dev)
-    ops.bn_next_bwd_prepare(n, bn4, dgamma, dbeta, c10)
-    ops.bn_lrelu_apply(y, bn4[0], bn4[1])
-    ops.bn_bwd_reduce(dz, y, bn4)
-    assert torch.equal(c10, bwd(False, lambda: ops.bn_bwd_reduce(dz, y, bn4))[3])
+    c10 = bwd(True, lambda kw: ops.bn_bwd_reduce(dz, y, bn4, **kw))[3]
+    assert ops.next_pending() == 0                            # nothing outlives the call it was passed to
     # dY without its (analytically zero) column sums
     dy0, dy1 = torch.empty_like(y), torch.empty_like(y)
     ops.bn_bwd_apply(dz, y, bn4, c10, dy0, torch.empty(2 * C, dtype=torch.float64, device=dev))

@@ -558,11 +558,10 @@ def test_timed_configuration_is_bit_identical_to_eager_at_144k(dev, dtype):
     assert all(np.isfinite(a[0]))
 
 
-@pytest.mark.parametrize("env", [{"DDMP_SPMM_STATS": "0"}, {"DDMP_EQUAL_WIDTH": "transform"},
-                                 {"DDMP_EQUAL_WIDTH": "transform", "DDMP_SPMM_STATS": "0"}])
+@pytest.mark.parametrize("env", [{"DDMP_UNFUSE": "stats"}, {"DDMP_UNFUSE": "equal_width"}, {"DDMP_UNFUSE": "equal_width,stats"}])
 def test_layer_order_and_statistics_switches_agree_with_the_default(dev, monkeypatch, env):
     """Round 4: the forward statistics of the transform-first layers come from the gather's epilogue by default
-    (DDMP_SPMM_STATS=0: the separate pass), equal-width layers aggregate first (DDMP_EQUAL_WIDTH=transform: the reference's own
+    (DDMP_UNFUSE=stats: the separate pass), equal-width layers aggregate first (DDMP_UNFUSE=equal_width: the reference's own
     order).  Same mathematics, other summation orders / kernels: the first iteration from identical weights agrees to float32
     rounding -- loss, outputs, and the gradients that iteration produced (seen through the Adam moments)."""
     from dual_dmp_amd.networks import PosNet, NormalNet
@@ -570,8 +569,7 @@ def test_layer_order_and_statistics_switches_agree_with_the_default(dev, monkeyp
     gt, noisy, smooth, data = _case(dev, "torus144k")
     runs = []
     for e in ({}, env):
-        for k in ("DDMP_SPMM_STATS", "DDMP_EQUAL_WIDTH"):
-            monkeypatch.delenv(k, raising=False)
+        monkeypatch.delenv("DDMP_UNFUSE", raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
         torch.manual_seed(5)
@@ -580,11 +578,12 @@ def test_layer_order_and_statistics_switches_agree_with_the_default(dev, monkeyp
         loss = tr.step().item()
         torch.cuda.synchronize()
         eng = tr.neng
-        if e.get("DDMP_SPMM_STATS") == "0":
+        off = e.get("DDMP_UNFUSE", "").split(",")
+        if "stats" in off:
             assert not any(eng.fuse_spmm_stats)
         elif not e:
             assert sum(eng.fuse_spmm_stats) >= 3, "the default does not take the statistics epilogue"
-        if e.get("DDMP_EQUAL_WIDTH") == "transform":
+        if "equal_width" in off:
             assert not any(eng.agg_first[l] for l in range(12) if eng.layout.cin_p[l] == eng.layout.cout[l])
         runs.append((loss, tr.pos.clone(), tr.norm.clone(), tr.m[0].clone(), tr.m[1].clone()))
         del tr, posnet, normnet
@@ -598,7 +597,7 @@ def test_layer_order_and_statistics_switches_agree_with_the_default(dev, monkeyp
 @pytest.mark.parametrize("which,dtype", [("grid", torch.float32), ("grid", torch.bfloat16), ("torus48k", torch.float32)])
 def test_launch_fusions_are_bit_identical(dev, monkeypatch, which, dtype):
     """Round 3: BatchNorm coefficients written by the second stage of the reduction that produced their sums
-    (DDMP_TAIL_FUSE) and all weight matrices split once per iteration in two launches (DDMP_PREP_WEIGHTS), both default on,
+    (DDMP_UNFUSE=tail) and all weight matrices split once per iteration in two launches (DDMP_UNFUSE=wprep), both default on,
     against one prepare kernel per BatchNorm and one split per GEMM call: the same iteration bit for bit -- on a small mesh
     (plain / wave-specialised GEMM routes) and from 20k rows (row-panel / row-register routes)."""
     from dual_dmp_amd.networks import PosNet, NormalNet
@@ -606,8 +605,7 @@ def test_launch_fusions_are_bit_identical(dev, monkeypatch, which, dtype):
     gt, noisy, smooth, data = _case(dev, which)
     runs = []
     for flag in ("0", "1"):
-        monkeypatch.setenv("DDMP_TAIL_FUSE", flag)
-        monkeypatch.setenv("DDMP_PREP_WEIGHTS", flag)
+        monkeypatch.setenv("DDMP_UNFUSE", "" if flag == "1" else "tail,wprep")
         torch.manual_seed(5)
         posnet, normnet = PosNet(dev, dtype=dtype), NormalNet(dev, dtype=dtype)
         tr = FusedTrainer(posnet, normnet, data, noisy, bnfloop=2, bnf_start_epoch=2)

@@ -12,40 +12,29 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 SWITCHES = [
-    {"DDMP_TN_NARROW_PANELS": "0"},            # 128 <-> 256 wgrads on the tiled bf16x6 kernel
-    {"DDMP_TN_PP": "0"},                       # wide wgrad: one segment order on all waves
     {"DDMP_SPMM_PATCH": "0"},                  # lean gather everywhere
     {"DDMP_SPMM_PATCH": "1"},                  # LDS-patch gather wherever it applies (incl. its fused-reduction form)
     {"DDMP_SPMM_PATCH_NE": "0"},               # ... with the entries read from LDS per slab
-    {"DDMP_SPMM_PATCH_FORMS": "0"},            # round-4 selection: no prologue / reduction at C = 512, no statistics form on it
-    {"DDMP_SPMM": "row"},                      # round-1 row kernel for every width
-    {"DDMP_SPMM_SL": "2"},                     # two 128-byte slabs per pass of the round-2 slab kernel
-    {"DDMP_ASYNC_WGRAD": "1"},                 # weight gradients on a further stream
-    {"DDMP_SPMM_LEAN": "0"},                   # round-2 slab gather
+    {"DDMP_SPMM_LEAN": "0"},                   # round-2 slab gather (the fallback of the lean kernel)
     {"DDMP_GEMM_RR": "0"},                     # row-panel instead of row-register GEMMs
-    {"DDMP_GEMM_BNRED": "0"},                  # dgrad without the reductions epilogue
-    {"DDMP_BNBWD_NARROW": "0", "DDMP_BNBWD_L0": "0"},      # narrow layers: bn_bwd_apply + plain GEMMs
-    {"DDMP_SPMM_BNBWD": "0"},                  # transform-first layers: bn_bwd_apply + plain gather
-    {"DDMP_TAIL_FUSE": "0", "DDMP_PREP_WEIGHTS": "0"},
     {"DDMP_GEMM_MODE": "6"},                   # bf16x6 everywhere
     {"DDMP_GEMM_PANEL": "0"},                  # tiled kernels instead of the row panels
-    {"DDMP_GEMM_WS": "0"},
-    {"DDMP_GEMM_BNRED_NARROW": "0"},
-    {"DDMP_RR_PM2_WIDE": "1"},                 # the two-half BatchNorm-backward dgrad on the row-register kernel
-    {"DDMP_SPMM_SLAB_GROUPS": "0"},
-    {"DDMP_SPMM_PATCH_MAXNNZ": "5"},           # LDS-patch gather on the face graph only
-    {"DDMP_SPMM_STATS": "0"},
-    {"DDMP_EQUAL_WIDTH": "transform"},
+    # DDMP_UNFUSE=<names>: fused routes composed from their parts instead (round 6: one switch for what were eleven)
+    {"DDMP_UNFUSE": "dgrad_red"},              # dgrad without the reductions epilogue
+    {"DDMP_UNFUSE": "dgrad_red_narrow"},
+    {"DDMP_UNFUSE": "bnbwd_narrow,bnbwd_l0"},  # narrow layers: bn_bwd_apply + plain GEMMs
+    {"DDMP_UNFUSE": "gather_bwd"},             # transform-first layers: bn_bwd_apply + plain gather
+    {"DDMP_UNFUSE": "tail,wprep"},
+    {"DDMP_UNFUSE": "stats"},
+    {"DDMP_UNFUSE": "equal_width"},            # equal-width layers transform first (the reference's own order)
+    {"DDMP_UNFUSE": "stats,gather_bwd,bnbwd_l0,bnbwd_narrow,dgrad_red,dgrad_red_narrow,tail,wprep"},   # everything composed
 ]
 BF16_SWITCHES = [
-    {"DDMP_SPMM_PATCH_FORMS": "7"},            # bf16 features stay off the LDS-patch gather (round-4 selection)
-    {"DDMP_BF16_SPMM_BNRED": "0"},             # backward reductions as separate passes
-    {"DDMP_BF16_FUSE": "0"},                   # no BatchNorm backward on the GEMM operand loads
-    {"DDMP_BF16_GEMM_BNRED": "1"},             # transform-first dgrads with the reductions epilogue (round 5; off by default)
-    {"DDMP_TN_DMA": "0"},
-    {"DDMP_SPMM_B16_VW": "4"},
+    {"DDMP_UNFUSE": "bf16_spmm_red"},          # backward reductions as separate passes
+    {"DDMP_UNFUSE": "bf16_gemm"},              # no BatchNorm backward on the GEMM operand loads
     {"DDMP_GEMM_RR": "0"},
     {"DDMP_SPMM_LEAN": "0"},
+    {"DDMP_SPMM_PATCH": "0"},
 ]
 
 
