@@ -64,17 +64,15 @@ def get_parser(real: bool):
 def _self_launch(argv, real, n):
     """``--gpus N`` without a launcher: become the parent of ``torch.distributed.run`` (this process has not initialised HIP;
     the children are started, never exec'd into)."""
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "main4real.py" if real else "main.py")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + list(sys.argv[1:] if argv is None else argv)
+    # the launcher picks its own free port on the loopback address (--standalone: a c10d rendezvous at localhost:0 -- no
+    # bind-then-close race with another process; --local-addr: the container's hostname may not resolve)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), script] + list(sys.argv[1:] if argv is None else argv)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -136,6 +134,9 @@ def run(argv=None, real: bool = False):
     if not torch.cuda.is_available():
         raise RuntimeError("the HIP path needs a GPU: there is no CPU fallback")
     device = torch.device("cuda:" + str(local_rank if world > 1 else args.gpu))
+    if world > 1 and rank == 0 and (args.gpu != 0 or args.no_graph):
+        print("[WARN]: --gpu / --no_graph have no effect with %d ranks: rank r runs on cuda:LOCAL_RANK, the partitioned trainer "
+              "launches eagerly (dual-dmp_amd/dist.py)" % world)
     torch.cuda.set_device(device)
     seed = args.seed
     if world > 1:

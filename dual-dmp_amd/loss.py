@@ -493,7 +493,8 @@ def bnf(fn, mesh, sigma_s=0.7, sigma_c=0.2, iter=1, device=None):
       * the new mesh's ``fc / fn / fa`` are recomputed after a sweep only when ``iter > 1`` (``:254-256``) -- with ``iter == 1``
         the returned mesh keeps the input's, exactly as the reference leaves them.
     ``fn``: tensor or ndarray; promoted to float64 (the reference keeps a float32 input for the first sweep's |n_j - n_i|:
-    float32 rounding of that distance only)."""
+    float32 rounding of that distance only).  Deviation by design: the reference's function is numpy on the CPU; this one raises
+    ``DdmpError`` without a GPU like everything else in the product path (no CPU fallback: DESIGN.md 1)."""
     import copy
     if device is None:
         device = fn.device if isinstance(fn, torch.Tensor) and fn.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -513,6 +514,15 @@ def bnf(fn, mesh, sigma_s=0.7, sigma_c=0.2, iter=1, device=None):
         mesh_fn = None
         corner_v = faces.reshape(-1)                             # corner 3 f + k belongs to vertex faces[f, k]
         corner_f = torch.arange(F, device=device).repeat_interleave(3)
+        # the reference walks the SET vf[v] (util/loss.py:243-244): a face that names a vertex twice (a degenerate face) counts
+        # once at that vertex -- corner pairs (v, f) de-duplicated
+        dup = (faces[:, 1] == faces[:, 0]) | (faces[:, 2] == faces[:, 0]) | (faces[:, 2] == faces[:, 1])
+        if bool(dup.any()):
+            keep = torch.ones((F, 3), dtype=torch.bool, device=device)
+            keep[:, 1] &= faces[:, 1] != faces[:, 0]
+            keep[:, 2] &= (faces[:, 2] != faces[:, 0]) & (faces[:, 2] != faces[:, 1])
+            keep = keep.reshape(-1)
+            corner_v, corner_f = corner_v[keep], corner_f[keep]
         for _ in range(int(iter)):
             fc_dist = (fc[f2f] - fc[:, None, :]).norm(dim=2)
             neig_fn = new_fn[f2f]
@@ -532,7 +542,7 @@ def bnf(fn, mesh, sigma_s=0.7, sigma_c=0.2, iter=1, device=None):
                 nrm = cr.norm(dim=1, keepdim=True)
                 fa = 0.5 * nrm[:, 0]
                 mesh_fn = cr / (nrm + 1e-24)
-        new_mesh = copy.copy(mesh)                               # (shares the connectivity tables; geometry replaced below)
+        new_mesh = copy.deepcopy(mesh)                           # (util/loss.py:200: the caller's mesh shares nothing with the result)
         new_mesh.vs = vs.cpu().numpy()
         new_mesh.fc = np.array(mesh.fc, dtype=np.float64) if mesh_fn is None else fc.cpu().numpy()
         new_mesh.fa = np.array(mesh.fa, dtype=np.float64) if mesh_fn is None else fa.cpu().numpy()

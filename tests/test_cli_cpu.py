@@ -250,3 +250,29 @@ def test_bench_parity_object_bounds():
     assert abs(v["hip"]["dnorm_rms"] - v["oracle_float32"]["dnorm_rms"]) < 0.5 * v["oracle_float32"]["dnorm_rms"]
     out = bench.parity_object(dict(hip, norm=norm + 2e-2 * torch.randn(norm.shape, generator=g)), noisy_ref)
     assert not out["vs_float64"]["hip_within_2x_of_the_float32_reference"] and not out["ok"]
+
+
+def test_self_launch_builds_the_launcher_command(monkeypatch):
+    """`main.py --gpus N` outside a launcher starts torch.distributed.run as a CHILD (never an exec: this process may not have
+    touched a GPU, the children do) with a standalone loopback rendezvous -- the launcher picks its own port -- and hands the
+    command line through."""
+    from dual_dmp_amd import cli
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(cli.subprocess, "run", fake_run)
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "5")
+    rc = cli._self_launch(["-i", "datasets/x", "--gpus", "4", "--iter", "20"], False, 4)
+    cmd = seen["cmd"]
+    assert rc == 7 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--standalone" in cmd
+    assert cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert "--master-port" not in cmd and cmd[-6:] == ["-i", "datasets/x", "--gpus", "4", "--iter", "20"]
+    assert cmd[-7].endswith("main.py") and os.path.exists(cmd[-7])
+    assert "RANK" not in seen["env"] and "WORLD_SIZE" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert cli._self_launch(["-i", "x"], True, 2) == 7 and seen["cmd"][-3].endswith("main4real.py")
