@@ -1172,6 +1172,17 @@ def make_distributed_trainer(n_mesh, s_mesh, dataset, device, rank, world, bnflo
     posnet, normnet = nets
     sharded = ShardedData(dataset, n_mesh, rank, world)
     if isinstance(backend, NativeComm) and backend.world_size > 1 and not kw.get("_skip_self_check"):
+        # the job will route every RCCL call of a communicator through its exchange stream (overlap_halo, the default with peers):
+        # the start-up check then runs through that stream too
+        import os
+        ov = kw.get("overlap_halo")
+        if ov is None:
+            ov = os.environ.get("DDMP_DIST_SPLIT", "1") != "0"
+        graph = kw.get("use_graph") if kw.get("use_graph") is not None else os.environ.get("DDMP_DIST_GRAPH", "0") == "1"
+        if ov and not graph:
+            backend.use_xs = True
+            if backend_pos is not None:
+                backend_pos.use_xs = True
         good = backend.self_check(sharded.fplan)
         if good and backend_pos is not None:                     # each alone, then both in flight at once
             good = backend_pos.self_check(sharded.vplan) and backend.self_check(sharded.fplan, backend_pos, sharded.vplan)
