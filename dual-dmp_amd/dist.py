@@ -371,10 +371,14 @@ class NativeComm:
             _lib.check(self.L.ddmp_comm_create(self.rank, self.world_size, ctypes.c_char_p(box[0]), ctypes.byref(h)), "ddmp_comm_create")
         self.h = h
         self._plans = {}
-        # Exchange stream (round 6, DistributedTrainer(overlap_halo=True)): EVERY RCCL call of this communicator is enqueued on
-        # one stream of its own, behind an event of the caller's stream, and the caller's stream waits for its completion event
-        # -- at once (all-reduces, all-gathers, blocking exchanges) or, for start_halo_overlapped, when the boundary rows are
-        # about to be aggregated.  One communicator <-> one stream, whatever stream the kernels run on; never under capture.
+        # Exchange stream (round 6, DistributedTrainer(overlap_halo=True)): an OVERLAPPED halo exchange (start_halo_overlapped) is
+        # enqueued on a stream of the communicator's own, behind an event of the caller's stream; the caller's stream waits for
+        # its completion event right before it aggregates the boundary rows.  Blocking collectives (all-reduces, all-gathers,
+        # ghost exchanges) stay on the caller's stream: routing them through the exchange stream as well was measured at one
+        # rank with the RCCL loopback -- two cross-queue hand-offs of ~10 us per collective, ~100 collectives per step: 10.5
+        # instead of 8.5 ms at 125k faces (profiles/r06_dist_overhead.txt).  RCCL serialises the operations of one communicator in
+        # issue order whatever streams they are enqueued on (NCCL's launch-order rule), and the issue order is the same on every
+        # rank.  Never under capture.
         self.use_xs = False
         self.xs = None
 
@@ -419,19 +423,21 @@ class NativeComm:
             ws = ops.Workspace.get(self.L.ddmp_halo_pack_bytes(h, t.shape[1], dt), t.device)     # (per stream: the exchange stream's own)
             _lib_check(self.L.ddmp_halo_exchange(self.h, h, ops._p(t), t.stride(0), t.shape[1], dt, ops._p(ws), ws.numel(),
                                                  ops._p(sums), 0 if sums is None else sums.numel(), ops._stream()), "ddmp_halo_exchange")
-        w = self._on_xs(go, defer)
-        return w if defer else t
+        if defer:
+            return self._on_xs(go, True)
+        go()
+        return t
 
     def all_reduce_sum(self, t):
         assert t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
-        self._on_xs(lambda: _lib_check(self.L.ddmp_comm_allreduce_sum(self.h, ops._p(t), t.numel(), 1 if t.dtype == torch.float64 else 0,
-                                                                      ops._stream()), "ddmp_comm_allreduce_sum"))
+        _lib_check(self.L.ddmp_comm_allreduce_sum(self.h, ops._p(t), t.numel(), 1 if t.dtype == torch.float64 else 0, ops._stream()),
+                   "ddmp_comm_allreduce_sum")
         return t
 
     def all_gather_rows(self, out, local):
         local = local.contiguous()
-        self._on_xs(lambda: _lib_check(self.L.ddmp_comm_allgather(self.h, ops._p(local), ops._p(out), local.numel() * local.element_size(),
-                                                                  ops._stream()), "ddmp_comm_allgather"))
+        _lib_check(self.L.ddmp_comm_allgather(self.h, ops._p(local), ops._p(out), local.numel() * local.element_size(), ops._stream()),
+                   "ddmp_comm_allgather")
         return out
 
     def barrier(self):

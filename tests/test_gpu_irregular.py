@@ -269,6 +269,64 @@ def test_gather_forms_on_random_csr_graphs(dev, seed, n, nc, band, C):
         _forms(dev, gr, C, dtype, tol)
 
 
+class GSlice(G):
+    """Rows [r0, r1) of a graph as a graph of their own (ops.Graph.from_csr_host(rows=...), ddmp_graph_create_csr_rows_host): the
+    interior / boundary halves of a partitioned graph (dist.py, round 6).  Output row i is node r0 + i; the columns keep the
+    numbering of the whole graph."""
+
+    def __init__(self, dev, rowptr, col, dinv, n_cols, r0, r1):
+        from dual_dmp_amd import ops
+        self.n, self.n_cols = r1 - r0, n_cols
+        rp = (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.int64)
+        cc = col[rowptr[r0]:rowptr[r1]]
+        self.max_nnz = int(np.diff(rp).max()) if self.n else 0
+        self.g = ops.Graph.from_csr_host(rowptr, col, dinv, n_cols, rows=(r0, r1))
+        rows = np.repeat(np.arange(self.n), np.diff(rp))
+        w = dinv.astype(np.float64)[rows + r0] * dinv.astype(np.float64)[cc]
+        self.A = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, cc.astype(np.int64)])), torch.from_numpy(w),
+                                         (self.n, n_cols)).coalesce()
+
+
+@pytest.fixture(scope="module")
+def sliced():
+    """CSR tables of the flipped 144,400-face mesh's two graphs in RCB order (host arrays, built once per module)."""
+    from dual_dmp_amd import ops, synth
+    v, f = synth.torus(380, 190)
+    f = synth.flip_edges(v, f, rounds=10, seed=1)
+    f = synth.add_hub(v, f, 1000, 24)
+    order = ops.rcb_order_host(v, 64).astype(np.int64)
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    v, f = v[order], inv[f]
+    f = f[ops.rcb_order_host(v[f].mean(1), 64)]
+    ei, fi = _vertex_edges(v, f)
+    return {"vert": _csr_of(ei, len(v)) + (len(v),), "face": _csr_of(fi, len(f)) + (len(f),)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C", [512, 256, 64])
+@pytest.mark.parametrize("which,cut", [("face", 131072), ("face", 70016), ("vert", 66048), ("vert", 640)])
+def test_gather_forms_on_row_slices_of_a_graph(dev, sliced, which, cut, C, dtype):
+    """Round 6: every form of the gather on the two row slices [0, cut) and [cut, n) of the flipped 144k-face mesh's graphs (cuts
+    at chunk multiples, as the interior-first order makes them; slices above and below the 64k-row threshold of the LDS-patch
+    tables, i.e. both kernels): against the float64 operator of the slice, and -- plain and prologue forms -- BIT for bit the
+    rows of the whole graph's output (a row's entries are summed in CSR order whichever chunk the row sits in)."""
+    from dual_dmp_amd import ops
+    rowptr, col, dinv, n = sliced[which]
+    whole = ops.Graph.from_csr_host(rowptr, col, dinv, n)
+    tol = 4e-3 if dtype == torch.bfloat16 else 1e-6
+    torch.manual_seed(C)
+    x = torch.randn(n, C).to(dtype).to(dev)
+    a, b, bias = (torch.rand(C) + 0.5).to(dev), torch.randn(C).to(dev), torch.randn(C).to(dev)
+    y_all = ops.spmm(whole, x)
+    yp_all = ops.spmm(whole, x, bias=bias, pro=(a, b))
+    for r0, r1 in ((0, cut), (cut, n)):
+        gs = GSlice(dev, rowptr, col, dinv, n, r0, r1)
+        _forms(dev, gs, C, dtype, tol)
+        assert torch.equal(ops.spmm(gs.g, x), y_all[r0:r1])
+        assert torch.equal(ops.spmm(gs.g, x, bias=bias, pro=(a, b)), yp_all[r0:r1])
+
+
 SWITCHES = [{"DDMP_SPMM_PATCH": "1"}, {"DDMP_SPMM_PATCH": "0"}, {"DDMP_SPMM_PATCH_NE": "0"}, {"DDMP_SPMM_LEAN": "0"},
             {"DDMP_SPMM_PATCH": "1", "DDMP_SPMM_PATCH_NE": "0"}]
 
