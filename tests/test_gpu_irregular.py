@@ -312,6 +312,8 @@ def test_gather_forms_on_row_slices_of_a_graph(dev, sliced, which, cut, C, dtype
     tables, i.e. both kernels): against the float64 operator of the slice, and -- plain and prologue forms -- BIT for bit the
     rows of the whole graph's output (a row's entries are summed in CSR order whichever chunk the row sits in)."""
     from dual_dmp_amd import ops
+    if C != 256 and any(k.startswith("DDMP_SPMM") for k in os.environ):
+        pytest.skip("switched re-runs of this file take the C = 256 cases only (suite time)")
     rowptr, col, dinv, n = sliced[which]
     whole = ops.Graph.from_csr_host(rowptr, col, dinv, n)
     tol = 4e-3 if dtype == torch.bfloat16 else 1e-6
