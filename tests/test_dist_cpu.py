@@ -19,6 +19,8 @@ def _mesh(kind="ico2"):
     if kind == "flip":                                           # irregular valence (round 5): flipped torus + a valence-16 hub
         v, f = synth.torus(14, 8)
         f = synth.add_hub(v, synth.flip_edges(v, f, rounds=8, seed=3), 5, 16)
+    elif kind == "torus48":                                      # 2304 faces: every rank of 2 has interior chunks on both graphs
+        v, f = synth.torus(48, 24)
     else:
         v, f = synth.icosphere(2) if kind == "ico2" else synth.open_grid(9, 7)
     v, f = synth.permute_vertices(v, f, 2)
@@ -213,7 +215,7 @@ def test_split_aggregation_matches_unsplit_and_unpartitioned(monkeypatch, oracle
             assert float((p1 - p0).abs().max()) < 5e-6 and float((n1 - n0).abs().max()) < 5e-6
 
 
-def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated"):
+def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated", kind="ico2"):
     try:
         os.environ["DDMP_DIST_INTERLEAVE"] = interleave
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -228,13 +230,15 @@ def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated"):
         for mod in (engine, trainer, networks):
             mod.ops = stub
         oracle = load_oracle()
-        noisy, smooth, data = _mesh("ico2")
+        noisy, smooth, data = _mesh(kind)
         results = {}
         if losses == "sharded":
             _sharded_rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, results, epoch0=0)
         else:
             _rank_run(rank, world, D.TorchDistComm(), noisy, smooth, data, 2, stub, oracle, results)
         out, pa, na = results[rank][:3]
+        if kind == "torus48":                                    # the split really happened (round 6: overlap mode with peers)
+            assert results[rank][3] == (True, True), results[rank][3]
         q.put((rank, [(l, p.numpy(), n.numpy()) for l, p, n in out], pa.numpy(), na.numpy()))
         dist.barrier()
         dist.destroy_process_group()
@@ -267,6 +271,33 @@ def test_gloo_world2_matches_unpartitioned(monkeypatch, oracle, interleave, loss
     [p.join(60) for p in procs]
     for r in range(2):
         _compare(ref[0], got[r], ref, "gloo rank%d" % r)
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize("interleave", ["0", "1"])
+def test_gloo_world2_split_aggregation_with_async_exchanges(monkeypatch, oracle, interleave):
+    """Round 6: the overlap mode over REAL torch.distributed collectives -- world size 2 over gloo on a mesh with interior chunks on
+    both ranks and both graphs (asserted in the workers): the halo exchange of every aggregation is started with async_op=True
+    (TorchDistComm.all_to_all_start), the interior rows are aggregated, the handle is waited for, the boundary rows follow; the
+    collectives of the two ranks meet in the same order.  Equal to the unpartitioned run like every partitioned test."""
+    import torch.multiprocessing as mp
+    import cpu_ops_stub as stub
+    _patch(monkeypatch.setattr, stub)
+    noisy, smooth, data = _mesh("torus48")
+    ref = _reference_run(noisy, smooth, data, 2, stub, oracle)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 200) + 200 * int(interleave)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, interleave, "replicated", "torus48")) for r in range(2)]
+    [p.start() for p in procs]
+    got = {}
+    for _ in range(2):
+        rank, out, pa, na = q.get(timeout=600)
+        assert pa is not None, out
+        got[rank] = ([(l, torch.from_numpy(p), torch.from_numpy(n)) for l, p, n in out], pa, na)
+    [p.join(60) for p in procs]
+    for r in range(2):
+        _compare(ref[0], got[r], ref, "gloo split rank%d" % r)
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
 
 
