@@ -44,4 +44,6 @@ def test_bench_line_has_the_contract_fields_at_20k_faces():
     assert abs(d["reference_run_blend_ms_per_step"] - (0.1 * d["gate_closed_ms_per_step"] + 0.9 * d["gate_open_ms_per_step"])) < 2e-3
     p = d["parity_1m"]
     assert p["ok"] and "UNPINNED" in p["what"] and p["faces"] == d["config"]["faces"]
+    t2 = p["iter2_teacher_forced"]                                  # the oracle's state after iteration 1 -> one HIP iteration
+    assert "error" not in t2 and t2["ok"] and t2["rel"] <= 1e-5, t2
     assert d["bf16"]["ms_per_step"] > 0 and d["gemm_scale_overflow"] is None
