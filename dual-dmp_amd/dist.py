@@ -376,9 +376,11 @@ class NativeComm:
         # its completion event right before it aggregates the boundary rows.  Blocking collectives (all-reduces, all-gathers,
         # ghost exchanges) stay on the caller's stream: routing them through the exchange stream as well was measured at one
         # rank with the RCCL loopback -- two cross-queue hand-offs of ~10 us per collective, ~100 collectives per step: 10.5
-        # instead of 8.5 ms at 125k faces (profiles/r06_dist_overhead.txt).  RCCL serialises the operations of one communicator in
-        # issue order whatever streams they are enqueued on (NCCL's launch-order rule), and the issue order is the same on every
-        # rank.  Never under capture.
+        # instead of 8.5 ms at 125k faces (profiles/r06_dist_overhead.txt).  No two operations of the communicator are ever in
+        # flight at once, whatever RCCL does across streams: the exchange stream waits for an event recorded on the caller's
+        # stream AFTER every earlier collective was enqueued there, and the caller's stream waits for the exchange's completion
+        # event (before the boundary rows) before it enqueues the next collective -- the events serialise them in issue order, and
+        # the issue order is the same on every rank.  Never under capture.
         self.use_xs = False
         self.xs = None
 
