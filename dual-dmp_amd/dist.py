@@ -926,10 +926,12 @@ class DistributedTrainer:
             mk = self.ops.Graph.from_csr_host
             return (mk(plan.rowptr, plan.col, plan.dinv, plan.n_cols, rows=(0, plan.n_int)),
                     mk(plan.rowptr, plan.col, plan.dinv, plan.n_cols, rows=(plan.n_int, plan.n_rows)), plan.n_int)
-        if getattr(self, "overlap_halo", False):
-            for b in {id(backend): backend, id(self.backend_pos): self.backend_pos}.values():
-                if hasattr(b, "use_xs") and torch.device(device).type == "cuda":
-                    b.use_xs = True                              # every RCCL call of the communicator on its exchange stream
+        # (the interleaved driver keeps one net's collective in flight while the other net issues its own: with ONE native
+        #  communicator that would put two of its operations in flight at once -- the exchange stream is for the plain drivers)
+        interleaved = os.environ.get("DDMP_DIST_INTERLEAVE", "0") == "1"
+        for b in {id(backend): backend, id(self.backend_pos): self.backend_pos}.values():
+            if hasattr(b, "use_xs"):
+                b.use_xs = bool(getattr(self, "overlap_halo", False)) and not interleaved and torch.device(device).type == "cuda"
         self.peng = GcnEngine(vg, POS_WIDTHS, 0, sd.z1.to(device), sd.x_pos.to(device),
                               comm=GraphComm(self.backend_pos, sd.vplan, device), n_total=sd.V,
                               dtype=getattr(posnet, "feature_dtype", torch.float32), split=halves(sd.vplan),
