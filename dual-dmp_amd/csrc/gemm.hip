@@ -352,13 +352,15 @@ TnPlan tn_plan(int64_t n_rows, int M, int K, bool narrow_panels = false) {
         p.n_tiles_m = (int)cdiv(M, p.tm);
         p.n_tiles_k = (int)cdiv(K, p.tk);
         const int tiles = p.n_tiles_m * p.n_tiles_k;
-        // one 512-thread workgroup per CU on THREE QUARTERS of the CUs; at least 256 rows (16 stages) per split; multiple of 8
-        // splits (XCD mapping).  Round 6: every split writes a tm x tk float32 partial panel that reduce_splits_kernel reads back --
-        // a fixed cost per launch (64 splits x 4 panels x 256 KB = 64 MB at 512 x 512) that does not shrink with the mesh.  With
-        // 3/4 of the splits (48 instead of 64) the step measured, interleaved: 1M faces 43.43 against 43.59 ms, 500k 22.75 / 22.94,
-        // 250k 12.34 / 12.58, 125k 7.14 / 7.37 (half: 43.66 / 22.86 / 12.23 / 7.21; 3/8: worse everywhere; twice: worse
-        // everywhere) -- the idle quarter of the CUs is not idle, the other net's kernels run there from the second stream.
-        int64_t s = std::min<int64_t>(std::max<int64_t>(1, (3 * kCu) / (4 * tiles)), std::max<int64_t>(1, n_rows / 256));
+        // one 512-thread workgroup per CU; at least 256 rows (16 stages) per split; multiple of 8 splits (XCD mapping).
+        // Round 6: every split writes a tm x tk float32 partial panel that reduce_splits_kernel reads back -- a fixed cost per launch
+        // (64 splits x 4 panels x 256 KB = 64 MB at 512 x 512) that does not shrink with the mesh.  Below 400k rows THREE QUARTERS
+        // of the splits (48 instead of 64): the step, interleaved A/B, 500k faces 22.75 against 22.94 ms, 250k 12.34 / 12.58, 125k
+        // 7.14 / 7.37 (half: 22.86 / 12.23 / 7.21; 3/8 and twice: worse everywhere) -- the idle quarter of the CUs is not idle, the
+        // other net's kernels run there from the second stream.  At 1M faces the same rule returned 0.16 ms of the step (43.43 /
+        // 43.59) but cost the wgrad family 0.9 ms when it runs ALONE (serialised profile: 10.99 against 10.1 ms): not taken there.
+        const int64_t cus = n_rows >= 400000 ? kCu : (3 * kCu) / 4;
+        int64_t s = std::min<int64_t>(std::max<int64_t>(1, cus / tiles), std::max<int64_t>(1, n_rows / 256));
         s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
         int64_t rps = cdiv(cdiv(n_rows, s), 32) * 32;
         p.rows_per_split = (int)rps;
