@@ -118,7 +118,7 @@ def copy_probe_rows(src, dst):
 
 def set_gemm_mode(mode: int):
     """6 = bf16x6 split MFMA (f32-class accuracy), 3 = bf16x3 (~2^-16), 0 = f32-input MFMA; 13 = f16x3 split MFMA
-    in the row-panel kernels (f32-class accuracy, scaled operands: see gemm_next_scales), bf16x6 elsewhere."""
+    in the row-panel kernels (f32-class accuracy, scaled operands: the ``scales=`` option of the GEMM calls), bf16x6 elsewhere."""
     check(_lib.lib().ddmp_set_gemm_mode(int(mode)), "ddmp_set_gemm_mode")
 
 

@@ -123,8 +123,8 @@ size_t ddmp_gemm_tn_workspace_bytes(int64_t n_rows, int M, int K);
  *   3  = bf16x3 (three products, ~2^-16 relative);   0 = f32-input MFMA (v_mfma_f32_32x32x2_f32).
  * Mode 13's power of two comes from the operand's absolute maximum, kept in a "scale slot" (device float[4]: {maximum
  * in use, maximum seen by the last kernels, overflow flag, healed events}).  By default the library measures it in a pre-pass over
- * the operand.  A training loop avoids that pass: ddmp_gemm_next_scales names persistent slots for the NEXT ddmp_gemm_*
- * call of this host thread (slot_a: the row operand A / dZ / G; slot_b: Z of the tn forms; prime != 0: measure now
+ * the operand.  A training loop avoids that pass: DDMP_OPT_SCALES of the *_o forms names persistent slots for THAT call
+ * (slot_a: the row operand A / dZ / G; slot_b: Z of the tn forms; prime != 0: measure now
  * anyway, e.g. first iteration), the GEMM kernels record the maximum they see, and ddmp_gemm_scales_roll, once per
  * iteration, makes it the next iteration's scale (6 bits of head-room).  An operand that still outgrows its scale raises
  * the slot's flag ([2]) and is HEALED inside the same ddmp_gemm_* call: the kernel is launched a second time, returns at
@@ -152,23 +152,16 @@ int ddmp_bn_prepare_f32(const double* sums /*[2C]*/, double n_total, int C, cons
                         float* running_var /*nullable*/, ddmp_stream stream);
 int ddmp_bn_lrelu_apply_f32(const float* Y, int64_t ldy, float* Z, int64_t ldz, int64_t n_rows, int C,
                             const float* scale, const float* shift, float slope, ddmp_stream stream);
-/* backward: sums2 = (sum g, sum g*yhat), g = dZ * LeakyReLU'(scale*y+shift), yhat = (y-mean)*rstd */
+/* backward reductions sums2 = (sum g, sum g*yhat), g = dZ * LeakyReLU'(scale*y+shift), yhat = (y-mean)*rstd: ddmp_bn_bwd_reduce
+ * (dtype-tagged, below) */
 /* sums2 -> dgamma, dbeta and the two folded constants of dY = scale*g + c1*y + c0 */
 int ddmp_bn_bwd_prepare_f32(const double* sums2, double n_total, int C, const float* scale, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, float* c1, float* c0,
                             ddmp_stream stream);
-/* Tail-fused coefficients (round 3): arm the NEXT call on this host thread that produces a float64 [2C] column reduction
- * (ddmp_bn_stats*, ddmp_gemm_nt_stats_*, ddmp_bn_bwd_reduce*, ddmp_spmm_bnred*, ddmp_gemm_nn_bnred_f32 / _bf16) so that the second
- * stage of that reduction ALSO writes what ddmp_bn_prepare_f32 / ddmp_bn_bwd_prepare_f32 would (same arithmetic, bitwise the
- * same values; the sums are still written) -- one launch less per BatchNorm and direction.  C must be the reduction's width.
- * No device work, no stream: the arguments are remembered until that call; ddmp_bn_next_cancel drops them. */
-/* Everything "armed for the next call" on this host thread -- ddmp_bn_next_* (bit 0), ddmp_gemm_next_scales (bit 1),
- * ddmp_gemm_next_prepared (bit 2) -- as a bit mask, and a cancel for all of it.  Rules of the armed state (ABI 2): it is
- * consumed or DROPPED by the next entry point of its family whether that call succeeds or returns an error; a BatchNorm
- * request is only attached to a reduction of its own width C and only when the call has a sums buffer; a host mirror that
- * arms and calls in two steps cancels in its error path (dual-dmp_amd/_lib.py: `check`).
- * DEPRECATED since ABI 3: the *_o entry points at the end of this header take the same requests as an explicit per-call
- * ddmp_opts argument; dual-dmp_amd/engine.py no longer arms anything. */
+/* Tail-fused coefficients (round 3) and the other per-call options are arguments of the *_o entry points at the end of this header
+ * (ABI 3); the ABI-2 calls that armed them "for the next call of this host thread" left the ABI in round 6 (they are the hidden
+ * implementation of the _o scopes: csrc/ddmp_internal.h).  Diagnostic: the bit mask of options still recorded for this host thread
+ * -- BatchNorm coefficients (bit 0), GEMM scale slots (bit 1), prepared weight planes (bit 2); 0 between calls. */
 int ddmp_next_pending(void);
 /* dY (gradient w.r.t. the conv output) and its column sums (= gradient of the conv bias; dbias_sums NULL: dY only -- behind
  * a BatchNorm those sums are zero in exact arithmetic) */
@@ -254,16 +247,16 @@ int ddmp_grad_clip_f32(float* g, int64_t n, const double* sumsq, float max_norm,
 int ddmp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, const double* clip_sumsq /*nullable*/, float max_norm,
                        ddmp_stream stream);
-/* ddmp_spmm_f32 (no bias, no prologue) whose output Y is a gradient dZ consumed next by a BatchNorm+LeakyReLU
- * backward: also returns that layer's column reductions sums2 = ddmp_bn_bwd_reduce_f32(Y, Yp, scale, shift, mean,
- * rstd) from the kernel's epilogue (float32 partials per 64-row chunk, summed in float64); other widths run the two
- * calls one after the other. */
+/* ddmp_spmm_bnred (dtype-tagged, below; + ddmp_spmm_bnred_ws_bytes): the aggregation (no bias, no prologue) whose output Y is a
+ * gradient dZ consumed next by a BatchNorm+LeakyReLU backward also returns that layer's column reductions sums2 =
+ * ddmp_bn_bwd_reduce(Y, Yp, scale, shift, mean, rstd) from the kernel's epilogue (float32 partials per 64-row chunk, summed in
+ * float64); other widths run the two calls one after the other. */
 /* GCNConv.propagate of a transform-first layer (forward) that also returns the BatchNorm statistics of its output
  * (float64 [2C]: column sums of Y and of Y^2 = ddmp_bn_stats_f32(Y)) from the gather kernel's epilogue (round 3).  `ref`
  * [C]: a per-column reference near the column means (the caller's previous batch means; zeros are valid): the kernel
  * sums (y - ref) and (y - ref)^2 in float32 over 16 rows at a time and in float64 from there on, and the shift is undone
  * exactly -- around ref those partial sums are well conditioned whatever mean / std is (float32-class statistics, as
- * nn.BatchNorm1d computes them).  Workspace: ddmp_spmm_bnred_workspace_bytes(n_rows, C).  Where the fused kernel does not
+ * nn.BatchNorm1d computes them).  Workspace: ddmp_spmm_bnred_ws_bytes(n_rows, C, DDMP_F32).  Where the fused kernel does not
  * apply (C % 32, misaligned, ref NULL) it runs ddmp_spmm_f32 + ddmp_bn_stats_f32. */
 int ddmp_spmm_stats_supported(int C);
 int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t ldx, float* Y, int64_t ldy, int C,
@@ -371,8 +364,9 @@ int ddmp_mad_f64(int64_t F, const float* n1 /*[F,3] f32*/, const double* n2 /*[F
 #define DDMP_F32 0
 #define DDMP_BF16 1
 
-/* nt / nn: K resp. M (the contraction) a multiple of 32 (nt also K = 8 | 16, the first layer), outputs <= 512 columns;
- * workspace >= ddmp_gemm_rows_bf16_workspace_bytes(K, M) holds the bf16 weight planes */
+/* bfloat16 features, plain GEMMs: through the dtype-tagged ddmp_gemm_nt / _nn / _tn below (nt / nn: K resp. M -- the contraction -- a
+ * multiple of 32, nt also K = 8 | 16: the first layer; outputs <= 512 columns; workspace >= ddmp_gemm_rows_ws_bytes(K, M, DDMP_BF16)
+ * holds the bf16 weight planes) */
 /* Fused forms on the row-register kernel (csrc/gemm_rr_b16.inc; round 3): the streaming BatchNorm passes of the bf16 step
  * folded into the GEMMs, as the *_f32 namesakes do for float32 features.
  *   ddmp_gemm_fused_bf16_supported  bit 0: ddmp_gemm_nt_stats_bf16, bit 1: the two *_bnbwd_bf16 forms exist AND pay for a
@@ -438,7 +432,6 @@ int ddmp_halo_exchange(ddmp_comm* comm, const ddmp_halo_plan* plan, void* T, int
                        size_t ws_bytes, double* sums /*nullable*/, int n_sums, ddmp_stream stream);
 int ddmp_comm_allreduce_sum(ddmp_comm* comm, void* buf, int64_t n, int is_f64, ddmp_stream stream);
 int ddmp_comm_allgather(ddmp_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, ddmp_stream stream);
-/* float32 <-> bfloat16 (round to nearest even) of n contiguous elements */
 /* a one-thread kernel named ddmp_trace_marker_kernel: brackets a region in a rocprofv3 kernel trace (measurement aid) */
 int ddmp_trace_marker(ddmp_stream stream);
 /* 0 for the product library; a bit mask of the timing-only ablation macros a diagnostic build was compiled with (such builds
@@ -451,6 +444,7 @@ int ddmp_copy_probe(const void* src, void* dst, int64_t bytes, int mode, ddmp_st
 /* ... and the same copy in the gather's access pattern: 64-row chunks of a row-major [n_rows, row_bytes] matrix walked one
  * 128-byte slab at a time (row_bytes a multiple of 128): the ceiling of that pattern, whatever the graph */
 int ddmp_copy_probe_rows(const void* src, void* dst, int64_t n_rows, int row_bytes, ddmp_stream stream);
+/* float32 -> bfloat16 (round to nearest even) of n contiguous elements */
 int ddmp_f32_to_bf16(const float* in, uint16_t* out, int64_t n, ddmp_stream stream);
 
 /* dtype-tagged forms (dtype = DDMP_F32 | DDMP_BF16): what a binding of the reference's GCNConv / BatchNorm1d / Linear
