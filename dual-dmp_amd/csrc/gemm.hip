@@ -371,9 +371,11 @@ TnPlan tn_plan(int64_t n_rows, int M, int K, bool narrow_panels = false) {
     p.n_tiles_m = (int)cdiv(M, bt);
     p.n_tiles_k = (int)cdiv(K, bt);
     const int tiles = p.n_tiles_m * p.n_tiles_k;
-    // aim at ~3 workgroups per CU; at least 128 rows per split (small meshes: a split of 512 rows is 32 dependent
-    // stages, 40-50 us per wgrad at 13k rows); multiple of 8 splits (XCD mapping)
-    int64_t want = std::max<int64_t>(1, (3 * kCu) / tiles);
+    // aim at ~3 workgroups per CU (2 below 30k rows, where EVERY wgrad runs here and the partial panels are the larger part of
+    // the work: 13k faces 2.62 against 2.66 ms per iteration on one stream in three interleaved rounds, 26k faces 3.56 / 3.62;
+    // profiles/r06_wgrad_splits_ab.txt); at least 128 rows per split (small meshes: a split of 512 rows is 32 dependent stages,
+    // 40-50 us per wgrad at 13k rows); multiple of 8 splits (XCD mapping)
+    int64_t want = std::max<int64_t>(1, ((n_rows < 30000 ? 2 : 3) * kCu) / tiles);
     int64_t max_by_rows = std::max<int64_t>(1, n_rows / 128);
     int64_t s = std::min(want, max_by_rows);
     s = std::max<int64_t>(kXcd, (s / kXcd) * kXcd);
