@@ -185,6 +185,7 @@ struct ddmp_graph {
     int32_t* rowptr;    // device [n_rows + 1]
     int32_t* col;       // device [nnz]
     float* dinv;        // device [n_cols]   deg^-1/2 (deg counts the self loop)
+    float* ew;          // device [nnz]: dinv[col[e]], the entry's weight as the gather kernels stage it (no col -> dinv chain per chunk)
     float* dinv_r;      // = dinv + row0: the factor of output row i (row0 > 0: a row SLICE of a local graph, see ddmp_graph_create_csr_rows_host)
     int max_row_nnz;
     // LDS-patch gather (spmm_patch.hip).  Per 64-row chunk: the sorted unique column ids it references ("patch") and, per CSR
@@ -195,6 +196,7 @@ struct ddmp_graph {
     int32_t* pl_ptr;    // device [n_chunks + 1]
     int32_t* pl_col;    // device [pl_ptr[n_chunks]]
     uint16_t* lcol;     // device [nnz]
+    int max_chunk_nnz;  // most CSR entries of a chunk the patch kernel takes (its LDS entry tables are sized for it)
     int max_patch;      // largest patch among the chunks the patch kernel takes (0: tables not built)
     int patch_kd;       // patch rows per LDS buffer / 32 (3..6), chosen so that at most ~1 % of the chunks are heavy
     int32_t* heavy;     // device [n_heavy]: the heavy chunks, ascending

@@ -148,6 +148,12 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
         (e = hipMemcpy(g->col, col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     if ((e = hipMemcpy(g->dinv, dinv, sizeof(float) * (size_t)n_cols, hipMemcpyHostToDevice)) != hipSuccess) goto fail;
     g->dinv_r = g->dinv + row0;                                  // output row i is node row0 + i of the column numbering
+    {   // the entries' weights dinv[col[e]] as the gather kernels stage them: no col -> dinv chain in a chunk's set-up
+        std::vector<float> ew((size_t)std::max<int64_t>(g->nnz, 1), 0.f);
+        for (int64_t e2 = 0; e2 < g->nnz; ++e2) ew[(size_t)e2] = dinv[col[e2]];
+        if ((e = hipMalloc((void**)&g->ew, sizeof(float) * ew.size())) != hipSuccess) goto fail;
+        if ((e = hipMemcpy(g->ew, ew.data(), sizeof(float) * ew.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+    }
     {   // patch tables (see ddmp_graph): skipped when the rows of a chunk fan out too far (unordered numbering)
         const int64_t n_chunks = (n_rows + ddmp::kChunkRows - 1) / ddmp::kChunkRows;
         // by default from 64k rows for graphs with at most 12 entries per row ON AVERAGE (mesh graphs: 4 and ~7; the LDS
@@ -195,6 +201,7 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
                     std::sort(tmp.begin(), tmp.end());
                     tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
                     max_patch = std::max(max_patch, (int)tmp.size());
+                    g->max_chunk_nnz = std::max(g->max_chunk_nnz, (int)(rowptr[r1] - rowptr[r0]));
                     for (int64_t e2 = rowptr[r0]; e2 < rowptr[r1]; ++e2)
                         lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
                     pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
@@ -288,6 +295,7 @@ extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
     if (g->pl_ptr) (void)hipFree(g->pl_ptr);
     if (g->pl_col) (void)hipFree(g->pl_col);
     if (g->lcol) (void)hipFree(g->lcol);
+    if (g->ew) (void)hipFree(g->ew);
     if (g->heavy) (void)hipFree(g->heavy);
     delete g;
     return DDMP_OK;

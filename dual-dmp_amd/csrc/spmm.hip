@@ -374,7 +374,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         const int want = std::min(n_sl, std::max(1, 2048 / n_list));
         const int per = (n_sl + want - 1) / want;
         const int groups_l = (n_sl + per - 1) / per;
-        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list, groups_l), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X,
+        hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(n_list, groups_l), dim3(256), 0, st, g->rowptr, g->col, g->ew, g->dinv, g->dinv_r, X,
                            ldx, Y, ldy, n, C, bias, ps, psh, slope, 0, n_list, chunk_list, red, bwd);
         LAUNCH_TRY();
         return DDMP_OK;
@@ -389,7 +389,7 @@ int launch_lean(const LeanPlan& lp, const ddmp_graph* g, const float* X, int64_t
         const int per = (n_slabs + want - 1) / want;
         groups = (n_slabs + per - 1) / per;
     }
-    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->dinv, g->dinv_r, X, ldx,
+    hipLaunchKernelGGL((spmm_lean_kernel<PRO, RED, BWD>), dim3(cpx * kXcd, groups), dim3(256), 0, st, g->rowptr, g->col, g->ew, g->dinv, g->dinv_r, X, ldx,
                        Y, ldy, n, C, bias, ps, psh, slope, cpx, lp.n_chunks, (const int*)nullptr, red, bwd);
     LAUNCH_TRY();
     return DDMP_OK;

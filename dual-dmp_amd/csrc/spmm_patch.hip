@@ -77,10 +77,10 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 template <typename T, int KD, bool PRO, int RED, int NB, int NE>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-    const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
+    const float* __restrict__ ew, const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
     const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
-    int chunks_per_xcd, int n_chunks, RedArgs red) {
+    int chunks_per_xcd, int n_chunks, int emax, RedArgs red) {
     constexpr int VW = Lane<T>::VW, CS = 8 * VW;                 // channels per 128-byte slab
     constexpr int PR = 32 * KD;                                  // patch rows per buffer
     constexpr int KR = RED == 1 ? 2 : 0;                         // copies per wave and slab of the chunk's own Yp rows
@@ -93,12 +93,11 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     static_assert(!RED || NB == 2, "the fused reduction's record stores are counted for two buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* bufs = smem;                                  // [kNB][kBuf]
-    float* s_w = reinterpret_cast<float*>(smem + kNB * kBuf);    // [kMaxE]
-    float* s_dinv = s_w + kMaxE;                                 // [kRB]
+    float* s_w = reinterpret_cast<float*>(smem + kNB * kBuf);    // [emax]: the most entries of a chunk of this graph (multiple of 64, <= kMaxE)
+    float* s_dinv = s_w + emax;                                  // [kRB]
     int* s_rowptr = reinterpret_cast<int*>(s_dinv + kRB);        // [kRB + 1] (+3 pad)
-    int* s_pl = s_rowptr + kRB + 4;                              // [PR]
-    unsigned short* s_lc = reinterpret_cast<unsigned short*>(s_pl + PR);      // [kMaxE]
-    int* s_perm = reinterpret_cast<int*>(s_lc + kMaxE);          // [kRB]: the chunk's rows, longest first (chunk_rank_desc)
+    unsigned short* s_lc = reinterpret_cast<unsigned short*>(s_rowptr + kRB + 4);      // [emax]
+    int* s_perm = reinterpret_cast<int*>(s_lc + emax);          // [kRB]: the chunk's rows, longest first (chunk_rank_desc)
     float* s_coef = reinterpret_cast<float*>(s_perm + kRB);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd (RED 2: ref)
     // RED: the four waves' partial sums of a slab, by slab parity: [2][4 waves][2 sums][CS]
     float* s_part = s_coef + (RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C;
@@ -112,37 +111,98 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane >> 3, sl = lane & 7;
 
-    for (int i = tid; i <= nr; i += 256) s_rowptr[i] = rowptr[r0 + i];
-    for (int i = tid; i < nr; i += 256) s_dinv[i] = dinv_r[r0 + i];
+    // Prologue (round 6): ONE round trip to the tables instead of four dependent ones.  The spans (patch list, CSR slice) come from
+    // uniform loads; the lane's KD patch rows go to REGISTERS first in program order -- the copies of slab 0 need nothing else and
+    // are issued as soon as those arrive --, every table of the chunk (row pointers, factors, the entries' patch indices and their
+    // weights `ew` = dinv[col[e]], precomputed per graph: no col -> dinv chain) is requested before that wait and lands in LDS
+    // while slab 0 travels.  (Before: row pointers + patch list -> barrier -> col -> dinv[col] -> barrier -> first copy.)
     const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
     if (np <= 0) return;                                         // a heavy chunk: the lean gather's (uniform: before any barrier)
-    for (int i = tid; i < PR; i += 256) s_pl[i] = pl_col[p0 + min(i, np - 1)];      // padded with the last row
-    for (int i = tid; i < C; i += 256) {
-        s_coef[i] = bias ? bias[i] : 0.f;
+    const int e0 = rowptr[r0];
+    const int ne = rowptr[r0 + nr] - e0;                         // <= kMaxE (graph.hip: a chunk with more entries is heavy)
+    const T* xlane = X + sl * VW;
+    const T* psrc[KD];                                           // the lane's patch rows (padded with the last row), + its 16 bytes
+#pragma unroll
+    for (int i = 0; i < KD; ++i) psrc[i] = xlane + (int64_t)pl_col[p0 + min((4 * i + wave) * 8 + grp, np - 1)] * ldx;
+    const int rp_t = tid <= nr ? rowptr[r0 + tid] : 0;
+    const int rp_n = (wave == 0 && lane < nr) ? rowptr[r0 + lane + 1] : 0;
+    const float dv_t = tid < nr ? dinv_r[r0 + tid] : 0.f;
+    unsigned short lc_t[4];
+    float w_t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid + 256 * k;
+        lc_t[k] = t < ne ? lcol[e0 + t] : (unsigned short)0;
+        w_t[k] = t < ne ? ew[e0 + t] : 0.f;
+    }
+    float co_t[4][RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1];      // coefficient columns tid, + 256, ... (C <= 1024)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k;
+        const bool in = i < C;
+        co_t[k][0] = (in && bias) ? bias[i] : 0.f;
         if (PRO) {
-            s_coef[C + i] = pscale[i];
-            s_coef[2 * C + i] = pshift[i];
+            co_t[k][1] = in ? pscale[i] : 0.f;
+            co_t[k][2] = in ? pshift[i] : 0.f;
         }
         if (RED == 1) {
-            s_coef[3 * C + i] = red.scale[i];
-            s_coef[4 * C + i] = red.shift[i];
-            s_coef[5 * C + i] = red.mean[i];
-            s_coef[6 * C + i] = red.rstd[i];
+            co_t[k][3] = in ? red.scale[i] : 0.f;
+            co_t[k][4] = in ? red.shift[i] : 0.f;
+            co_t[k][5] = in ? red.mean[i] : 0.f;
+            co_t[k][6] = in ? red.rstd[i] : 0.f;
         }
-        if (RED == 2) s_coef[3 * C + i] = red.mean[i];
+        if (RED == 2) co_t[k][3] = in ? red.mean[i] : 0.f;
     }
-    __syncthreads();
+    const int n_slabs = C / CS;
+    const T* yplane = RED == 1 ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
+    // copies of slab s into buffer b: wave w, instruction i covers patch rows (4 i + w) * 8 .. + 7
+    auto copy = [&](int s, unsigned char* dst) {
+#pragma unroll
+        for (int i = 0; i < KD; ++i) dma16(psrc[i] + s * CS, dst + (4 * i + wave) * 8 * 128);
+        if (RED == 1) {
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                const int j0 = (4 * i + wave) * 8;                // own rows j0 .. j0 + 7 of the chunk
+                const int row = r0 + min(j0 + grp, nr - 1);
+                dma16(yplane + (int64_t)row * red.ldyp + s * CS, dst + PR * 128 + j0 * 128);
+            }
+        }
+    };
+    // The slab loop is unrolled over the buffers with COMPILE-TIME buffer addresses: the compiler orders a ds_read
+    // behind every LDS-DMA it cannot prove disjoint (a run-time buffer index costs a vmcnt(0) -- a full drain -- before
+    // the first read of every slab; measured 2x on the whole kernel).
+#pragma unroll
+    for (int i = 0; i < kNB - 1; ++i)
+        if (i < n_slabs) copy(i, bufs + i * kBuf);
+    if (tid <= nr) s_rowptr[tid] = rp_t;
+    if (tid < nr) s_dinv[tid] = dv_t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tid + 256 * k;
+        if (t < ne) {
+            s_lc[t] = lc_t[k];
+            s_w[t] = w_t[k];
+        }
+        if (t < C) {
+            s_coef[t] = co_t[k][0];
+            if (PRO) {
+                s_coef[C + t] = co_t[k][1];
+                s_coef[2 * C + t] = co_t[k][2];
+            }
+            if (RED == 1) {
+                s_coef[3 * C + t] = co_t[k][3];
+                s_coef[4 * C + t] = co_t[k][4];
+                s_coef[5 * C + t] = co_t[k][5];
+                s_coef[6 * C + t] = co_t[k][6];
+            }
+            if (RED == 2) s_coef[3 * C + t] = co_t[k][3];
+        }
+    }
     if (wave == 0) {                                             // rows of similar length share a wave (see chunk_rank_desc)
-        const int nn_l = lane < nr ? s_rowptr[lane + 1] - s_rowptr[lane] : -4;
+        const int nn_l = lane < nr ? rp_n - rp_t : -4;
         s_perm[chunk_rank_desc(min((nn_l + 3) >> 2, 31), lane)] = lane;
     }
-    const int e0 = s_rowptr[0];
-    const int ne = s_rowptr[nr] - e0;                            // <= kMaxE (graph.hip: a chunk with more entries is heavy)
-    for (int t = tid; t < ne; t += 256) {
-        s_lc[t] = lcol[e0 + t];
-        s_w[t] = dinv[col[e0 + t]];
-    }
-    __syncthreads();                                             // (plain loads above: all waited for by now)
+    __syncthreads();                                             // (the LDS tables; the copies above are waited for in the slab loop)
     int rows[2];                                                 // this lane's two rows (local indices; clamped on a ragged chunk)
 #pragma unroll
     for (int q = 0; q < 2; ++q) rows[q] = s_perm[min(wave * 16 + grp + 8 * q, nr - 1)];
@@ -176,34 +236,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         nmax = __builtin_amdgcn_readfirstlane(nmax);
     }
 
-    const int n_slabs = C / CS;
-    const T* xlane = X + sl * VW;
-    const T* yplane = RED == 1 ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
-    // copies of slab s into buffer b: wave w, instruction i covers patch rows (4 i + w) * 8 .. + 7
-    auto copy = [&](int s, unsigned char* dst) {
-#pragma unroll
-        for (int i = 0; i < KD; ++i) {
-            const int j0 = (4 * i + wave) * 8;
-            const int row = s_pl[j0 + grp];
-            dma16(xlane + (int64_t)row * ldx + s * CS, dst + j0 * 128);
-        }
-        if (RED == 1) {
-#pragma unroll
-            for (int i = 0; i < KR; ++i) {
-                const int j0 = (4 * i + wave) * 8;                // own rows j0 .. j0 + 7 of the chunk
-                const int row = r0 + min(j0 + grp, nr - 1);
-                dma16(yplane + (int64_t)row * red.ldyp + s * CS, dst + PR * 128 + j0 * 128);
-            }
-        }
-    };
     const bool full = nr == kRB;                                 // a ragged last chunk stores less: wait for everything
 
-    // The slab loop is unrolled over the four buffers with COMPILE-TIME buffer addresses: the compiler orders a ds_read
-    // behind every LDS-DMA it cannot prove disjoint (a run-time buffer index costs a vmcnt(0) -- a full drain -- before
-    // the first read of every slab; measured 2x on the whole kernel).
-#pragma unroll
-    for (int i = 0; i < kNB - 1; ++i)
-        if (i < n_slabs) copy(i, bufs + i * kBuf);
     // RED: ONE partial record per channel and chunk (as the lean gather writes them): the four waves' sums of slab s meet in
     // LDS, every wave adds them up for a quarter of the slab's 2 CS values (fixed order, float64, rounded once) and stores
     // that quarter -- one VMEM store per wave and slab, counted in the waits above
@@ -366,17 +400,17 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         __syncthreads();
         record(n_slabs - 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no copy outlives the workgroup's LDS
+    // (every copy was waited for by the slab that reads it; what is in flight here are stores: nothing to wait for)
 }
 
 // (two LDS buffers: three and four measured slower, profiles/r02_experiments)
 
 template <typename T, int KD, bool PRO, int RED, int NB>
-size_t patch2_lds(int C) {
+size_t patch2_lds(int C, int emax) {
     const int PR = 32 * KD;
     const size_t buf = (size_t)PR * 128 + (RED == 1 ? kRB * 128 : 0);
     const size_t cs = 128 / sizeof(T);
-    return NB * buf + kMaxE * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)PR * 4 + kMaxE * 2 + kRB * 4 +
+    return NB * buf + (size_t)emax * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)emax * 2 + kRB * 4 +
            (size_t)(RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C * 4 + (RED ? 2 * 4 * 2 * cs * 4 : 0);
 }
 
@@ -386,7 +420,10 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
-    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C);   // (the same for every NE)
+    // the entry tables hold the graph's largest taken chunk (face graph: 256 entries, not the 1024 a chunk may have at most: 4.5 KB
+    // less, a third workgroup per CU for the fused reduction at C = 256)
+    const int emax = std::min(kMaxE, std::max(64, (g->max_chunk_nnz + 63) / 64 * 64));
+    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C, emax);   // (the same for every NE)
     auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB, NE>;
     // > 64 KB of dynamic LDS needs the attribute, once per kernel AND device (a second device of the same process -- threaded
     // ranks -- has its own copy of the function)
@@ -401,8 +438,8 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
         }
         attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, X,
-                       ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, red);
+    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->ew, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, X,
+                       ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, emax, red);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -468,9 +505,11 @@ extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, i
     if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || !g->lcol) return 0;
     if (has_red == 1 && has_pro) return 0;                       // (no such form)
     if (patch_mode() == 3) {
-        // measured selection (by_patch's note, patch_forms): float32, C >= 256; row lengths are not a condition since round 5
-        // (DDMP_SPMM_PATCH_MAXNNZ=n keeps the A/B switch "graphs with longer rows stay lean")
-        if (g->max_row_nnz > patch_max_nnz() || C < 256) return 0;
+        // measured selection (by_patch's note, patch_forms); row lengths are not a condition since round 5
+        // round 6: float32 from C = 128 -- with the one-round-trip set-up the kernel wins there too (us per launch patch | lean, 1M faces,
+        // RCB order, cold buffers: face prologue 206 | 224, statistics 226 | 244, reduction 310 | 323; vertex 138 | 149, 158 | 167,
+        // 197-206 | 200); at C = 64 it loses the prologue and reduction forms (profiles/r06_gather_prologue_ab.txt)
+        if (g->max_row_nnz > patch_max_nnz() || C < (dtype == DDMP_F32 ? 128 : 256)) return 0;
         // bfloat16 features (round 5, 1M faces, RCB numbering, us per launch patch | slab kernel): plain C = 512 face 420 | 457,
         // vertex 251 | 311; prologue face 434 | 550, vertex 414 | 428; statistics face 546 | 617, vertex 377 | 425 (C = 256 alike);
         // the fused reduction LOSES there (face 819 | 730, vertex 493 | 448) and stays on the slab kernel

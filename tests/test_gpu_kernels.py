@@ -105,9 +105,12 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         sel = L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1       # (144,400 faces / 72,200 vertices: both from 64k rows)
         assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
         if os.environ.get("DDMP_SPMM_PATCH") is None:
-            # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256
-            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 0
-            assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0
+            # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256;
+            # round 6 (one-round-trip chunk set-up): float32 from C = 128, nothing at C = 64, bfloat16 as before
+            assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 1
+            assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 1, 2) == 1
+            assert L.ddmp_spmm_patch_selected(g._h, 64, 0, 0, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 64, 0, 0, 1) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 128, 1, 0, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0
             assert L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 1, 2) == 1    # bf16
             assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 2) == 1
         # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
@@ -116,7 +119,7 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         deg = torch.zeros(n, dtype=torch.float64).index_add_(0, dst, torch.ones(len(dst), dtype=torch.float64))
         w = deg[src].pow(-0.5) * deg[dst].pow(-0.5)
         A = torch.sparse_coo_tensor(torch.stack([dst, src]), w, (n, n)).coalesce()
-        for C in (256, 512):
+        for C in (128, 256, 512):
             torch.manual_seed(C)
             x = torch.randn(n, C)
             a, b, bias = torch.rand(C) + 0.5, torch.randn(C), torch.randn(C)
