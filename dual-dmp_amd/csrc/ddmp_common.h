@@ -210,4 +210,7 @@ constexpr int kPatchNotApplicable = -100;
 int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t ldy, int C, int dtype, const float* bias,
                const float* ps, const float* psh, float slope, const void* red_Yp, int64_t red_ldyp, const float* red_scale,
                const float* red_shift, const float* red_mean, const float* red_rstd, float* red_part, hipStream_t st);
+// the BatchNorm backward on the gather (ddmp_spmm_bnbwd_f32), LDS-patch form; heavy chunks are the caller's
+int spmm_patch_bwd(const ddmp_graph* g, const void* dZ, int64_t lddz, const void* Yb, int64_t ldyb, void* out, int64_t ld_out, int C,
+                   int dtype, const float* a, const float* b, const float* c1, const float* c0, float slope, hipStream_t st);
 }

@@ -609,6 +609,13 @@ extern "C" int ddmp_spmm_bnbwd_f32(const ddmp_graph* g, const float* dZ, int64_t
     const int cpx = (int)cdiv(n_chunks, kXcd);
     BnBwdGather bwd{Yb, ldyb, c1, c0};
     const LeanPlan lp = lddz == ldyb ? lean_plan(g, lddz, ld_out, C, 4) : LeanPlan{0, 0};   // one staged offset serves both matrices
+    if (lp.kind || g->n_heavy == 0) {                            // LDS-patch form where it applies; its heavy chunks: the lean form
+        const int rc = ddmp::spmm_patch_bwd(g, dZ, lddz, Yb, ldyb, out, ld_out, C, DDMP_F32, a, b, c1, c0, slope, (hipStream_t)stream);
+        if (rc == DDMP_OK && g->n_heavy > 0)
+            return launch_lean<true, 0, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd,
+                                              g->heavy, g->n_heavy);
+        if (rc != ddmp::kPatchNotApplicable) return rc;
+    }
     if (lp.kind) return launch_lean<true, 0, true>(lp, g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRed(), bwd);
     hipLaunchKernelGGL((spmm_slab_kernel<8, 4, 1, true, 1, false, true>), dim3(cpx * kXcd), dim3(256), 0,
                        (hipStream_t)stream, g->rowptr, g->col, g->dinv, g->dinv_r, dZ, lddz, out, ld_out, n, C, (const float*)nullptr,

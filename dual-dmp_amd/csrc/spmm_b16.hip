@@ -496,5 +496,12 @@ extern "C" int ddmp_spmm_bnbwd_bf16(const ddmp_graph* g, const uint16_t* dZ, int
     ARG_TRY(g && dZ && Yb && out && a && b && c1 && c0 && dZ != out && Yb != out && shape_ok(dZ, lddz, out, ld_out, C));
     ARG_TRY(ldyb >= C && ldyb % 8 == 0 && b16_aligned(Yb) && coef_ok(a) && coef_ok(b) && coef_ok(c1) && coef_ok(c0));
     BnBwdGatherB bwd{Yb, ldyb, c1, c0};
+    {   // LDS-patch form where it applies (round 6); its heavy chunks: the slab kernel over the list
+        const int rc = ddmp::spmm_patch_bwd(g, dZ, lddz, Yb, ldyb, out, ld_out, C, DDMP_BF16, a, b, c1, c0, slope, (hipStream_t)stream);
+        if (rc == DDMP_OK && g->n_heavy > 0)
+            return dispatch_b16<true, 0, true>(g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRedB(), bwd, g->heavy,
+                                               g->n_heavy);
+        if (rc != ddmp::kPatchNotApplicable) return rc;
+    }
     return dispatch_b16<true, 0, true>(g, dZ, lddz, out, ld_out, C, nullptr, a, b, slope, (hipStream_t)stream, BnRedB(), bwd);
 }

@@ -62,6 +62,12 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
     float* part;
 };
 
+struct BwdArgs {                    // BatchNorm backward on the gather (see BnBwdGather in spmm.hip): the operand is rebuilt from (X = dZ, Yb)
+    const void* Yb;
+    int64_t ldyb;
+    const float *c1, *c0;
+};
+
 // KD: copies per wave and slab of the patch (8 rows each, 4 waves): the patch buffer holds 32 KD rows
 // NB: patch buffers (2: 41-57 KB of LDS per workgroup, two to three workgroups per CU hide each other's copy latency and
 // barriers; 4: the round-2 form, one workgroup per CU pipelining three slabs ahead)
@@ -74,21 +80,27 @@ struct RedArgs {                    // fused BatchNorm-backward column reduction
 // computed by the lean gather.  Rows without entries (csr_host graphs) are legal: weight 0 on patch row 0.
 // RED: 0 | 1 the BatchNorm-backward reductions of the output (RedArgs; the chunk's own Yp rows ride the DMA ring) | 2 (round 5)
 // the BatchNorm STATISTICS of the output around the per-column reference red.mean (see spmm_lean.inc): sum (y - ref), (y - ref)^2
-template <typename T, int KD, bool PRO, int RED, int NB, int NE>
+// BWD (round 6; measured first in round 5, experiments/r05): the gathered operand is the BatchNorm + LeakyReLU BACKWARD of (X = dZ, Yb),
+// rebuilt per entry as in spmm_lean_kernel<true, 0, true> (same expression, same order: bit-identical sums) -- the patch rows of Yb
+// ride the DMA ring in a second half of every buffer (twice the copies, twice the LDS reads, no second trip through the L1 per
+// entry); a, b = pscale, pshift.  No fused epilogue.
+template <typename T, int KD, bool PRO, int RED, int NB, int NE, bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
     const float* __restrict__ ew, const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
     const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
-    int chunks_per_xcd, int n_chunks, int emax, RedArgs red) {
+    int chunks_per_xcd, int n_chunks, int emax, RedArgs red, BwdArgs bw = BwdArgs()) {
+    static_assert(!BWD || (PRO && !RED), "BWD: coefficients a, b as the prologue's, no epilogue");
     constexpr int VW = Lane<T>::VW, CS = 8 * VW;                 // channels per 128-byte slab
     constexpr int PR = 32 * KD;                                  // patch rows per buffer
+    constexpr int KX = BWD ? 2 * KD : KD;                        // patch copies per wave and slab (BWD: X and Yb)
     constexpr int KR = RED == 1 ? 2 : 0;                         // copies per wave and slab of the chunk's own Yp rows
     constexpr int NST = 2;                                       // output stores per lane and slab
     constexpr int NSR = RED ? 1 : 0;                             // + the wave's quarter of the previous slab's partial record
-    constexpr int kBuf = PR * 128 + (RED == 1 ? kRB * 128 : 0);  // bytes per buffer
+    constexpr int kBuf = PR * 128 * (BWD ? 2 : 1) + (RED == 1 ? kRB * 128 : 0);  // bytes per buffer
     constexpr int kNB = NB;
-    constexpr int NWAIT = (KD + KR) * (kNB - 2) + (NST + NSR) * (kNB - 1);   // VMEM operations younger than the copies of slab s
+    constexpr int NWAIT = (KX + KR) * (kNB - 2) + (NST + NSR) * (kNB - 1);   // VMEM operations younger than the copies of slab s
     static_assert(NWAIT <= 63, "vmcnt range");
     static_assert(!RED || NB == 2, "the fused reduction's record stores are counted for two buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     int* s_perm = reinterpret_cast<int*>(s_lc + emax);          // [kRB]: the chunk's rows, longest first (chunk_rank_desc)
     float* s_coef = reinterpret_cast<float*>(s_perm + kRB);      // [nco][C]: bias | pscale, pshift | scale, shift, mean, rstd (RED 2: ref)
     // RED: the four waves' partial sums of a slab, by slab parity: [2][4 waves][2 sums][CS]
-    float* s_part = s_coef + (RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C;
+    float* s_part = s_coef + (RED == 1 ? 7 : RED == 2 ? 4 : BWD ? 5 : PRO ? 3 : 1) * C;
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
@@ -122,8 +134,13 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int ne = rowptr[r0 + nr] - e0;                         // <= kMaxE (graph.hip: a chunk with more entries is heavy)
     const T* xlane = X + sl * VW;
     const T* psrc[KD];                                           // the lane's patch rows (padded with the last row), + its 16 bytes
+    const T* pysrc[BWD ? KD : 1];                                // BWD: the same rows of Yb
 #pragma unroll
-    for (int i = 0; i < KD; ++i) psrc[i] = xlane + (int64_t)pl_col[p0 + min((4 * i + wave) * 8 + grp, np - 1)] * ldx;
+    for (int i = 0; i < KD; ++i) {
+        const int prow = pl_col[p0 + min((4 * i + wave) * 8 + grp, np - 1)];
+        psrc[i] = xlane + (int64_t)prow * ldx;
+        if (BWD) pysrc[BWD ? i : 0] = static_cast<const T*>(bw.Yb) + sl * VW + (int64_t)prow * bw.ldyb;
+    }
     const int rp_t = tid <= nr ? rowptr[r0 + tid] : 0;
     const int rp_n = (wave == 0 && lane < nr) ? rowptr[r0 + lane + 1] : 0;
     const float dv_t = tid < nr ? dinv_r[r0 + tid] : 0.f;
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         lc_t[k] = t < ne ? lcol[e0 + t] : (unsigned short)0;
         w_t[k] = t < ne ? ew[e0 + t] : 0.f;
     }
-    float co_t[4][RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1];      // coefficient columns tid, + 256, ... (C <= 1024)
+    float co_t[4][RED == 1 ? 7 : RED == 2 ? 4 : BWD ? 5 : PRO ? 3 : 1];      // coefficient columns tid, + 256, ... (C <= 1024)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = tid + 256 * k;
@@ -152,13 +169,20 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             co_t[k][6] = in ? red.rstd[i] : 0.f;
         }
         if (RED == 2) co_t[k][3] = in ? red.mean[i] : 0.f;
+        if (BWD) {
+            co_t[k][BWD ? 3 : 0] = in ? bw.c1[i] : 0.f;
+            co_t[k][BWD ? 4 : 0] = in ? bw.c0[i] : 0.f;
+        }
     }
     const int n_slabs = C / CS;
     const T* yplane = RED == 1 ? static_cast<const T*>(red.Yp) + sl * VW : nullptr;
     // copies of slab s into buffer b: wave w, instruction i covers patch rows (4 i + w) * 8 .. + 7
     auto copy = [&](int s, unsigned char* dst) {
 #pragma unroll
-        for (int i = 0; i < KD; ++i) dma16(psrc[i] + s * CS, dst + (4 * i + wave) * 8 * 128);
+        for (int i = 0; i < KD; ++i) {
+            dma16(psrc[i] + s * CS, dst + (4 * i + wave) * 8 * 128);
+            if (BWD) dma16(pysrc[BWD ? i : 0] + s * CS, dst + PR * 128 + (4 * i + wave) * 8 * 128);
+        }
         if (RED == 1) {
 #pragma unroll
             for (int i = 0; i < KR; ++i) {
@@ -196,6 +220,10 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                 s_coef[6 * C + t] = co_t[k][6];
             }
             if (RED == 2) s_coef[3 * C + t] = co_t[k][3];
+            if (BWD) {
+                s_coef[3 * C + t] = co_t[k][BWD ? 3 : 0];
+                s_coef[4 * C + t] = co_t[k][BWD ? 4 : 0];
+            }
         }
     }
     if (wave == 0) {                                             // rows of similar length share a wave (see chunk_rank_desc)
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         // the copies of slab s have landed (mine: counted wait; everybody's: barrier); all waves are done with slab s-1
         // (counted: the kNB-2 younger slabs' copies and the stores issued since stay in flight; the first kNB-1 slabs
         //  have fewer stores behind them, the last ones fewer copies: exact counts or a full drain)
-        constexpr int ND = (KD + KR) * (kNB - 2);
+        constexpr int ND = (KX + KR) * (kNB - 2);
         if (!full || s + kNB - 1 > n_slabs) wait_vm_barrier<0>();
         else if (s == 0) wait_vm_barrier<ND>();
         else if (s == 1 && (kNB > 2 || RED)) wait_vm_barrier<ND + NST>();    // (RED: slab 0 had no record to store)
@@ -274,6 +302,16 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                 const float4 c = *reinterpret_cast<const float4*>(&s_coef[2 * C + off + 4 * q]);
                 pa[4 * q] = a.x; pa[4 * q + 1] = a.y; pa[4 * q + 2] = a.z; pa[4 * q + 3] = a.w;
                 psh[4 * q] = c.x; psh[4 * q + 1] = c.y; psh[4 * q + 2] = c.z; psh[4 * q + 3] = c.w;
+            }
+        }
+        float kc1[VW], kc0[VW];
+        if (BWD) {
+#pragma unroll
+            for (int q = 0; q < VW / 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_coef[3 * C + off + 4 * q]);
+                const float4 c = *reinterpret_cast<const float4*>(&s_coef[4 * C + off + 4 * q]);
+                kc1[4 * q] = a.x; kc1[4 * q + 1] = a.y; kc1[4 * q + 2] = a.z; kc1[4 * q + 3] = a.w;
+                kc0[4 * q] = c.x; kc0[4 * q + 1] = c.y; kc0[4 * q + 2] = c.z; kc0[4 * q + 3] = c.w;
             }
         }
         float q0[VW], q1[VW];
@@ -297,18 +335,26 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                     // the quad's fourth entry is padding for EVERY row of the wave when nmax == k0 + 3 (the 7-entry vertex graph of
                     // a regular mesh, as in the lean kernel): its LDS read and its four FMAs with weight 0 are skipped wave-wide
                     const bool fourth = k0 + 3 < nmax;           // (uniform)
-                    uint4 v[4];
+                    uint4 v[4], vy[BWD ? 4 : 1];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) v[k] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + k]);
-                    if (fourth) v[3] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + 3]);
+                    for (int k = 0; k < 3; ++k) {
+                        v[k] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + k]);
+                        if (BWD) vy[BWD ? k : 0] = *reinterpret_cast<const uint4*>(pq + PR * 128 + lo[q][k0 + k]);
+                    }
+                    if (fourth) {
+                        v[3] = *reinterpret_cast<const uint4*>(pq + lo[q][k0 + 3]);
+                        if (BWD) vy[BWD ? 3 : 0] = *reinterpret_cast<const uint4*>(pq + PR * 128 + lo[q][k0 + 3]);
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (k == 3 && !fourth) break;
-                        float t[VW];
+                        float t[VW], y[VW];
                         Lane<T>::unpack(v[k], t);
+                        if (BWD) Lane<T>::unpack(vy[BWD ? k : 0], y);
 #pragma unroll
                         for (int j = 0; j < VW; ++j) {
-                            const float x = PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
+                            const float x = BWD ? fmaf(pa[j], t[j] * lrelu_grad(fmaf(y[j], pa[j], psh[j]), slope), fmaf(kc1[j], y[j], kc0[j]))
+                                                : PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
                             acc[j] = fmaf(wjr[q][k0 + k], x, acc[j]);
                         }
                     }
@@ -318,7 +364,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
             while (es < ee) {
                 int li[4];
                 float wj[4];
-                uint4 v[4];
+                uint4 v[4], vy[BWD ? 4 : 1];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int ek = min(es + k, ee - 1);
@@ -326,14 +372,19 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
                     wj[k] = (es + k < ee) ? s_w[ek] : 0.f;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(pb + li[k] * 128);
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = *reinterpret_cast<const uint4*>(pb + li[k] * 128);
+                    if (BWD) vy[BWD ? k : 0] = *reinterpret_cast<const uint4*>(pb + PR * 128 + li[k] * 128);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float t[VW];
+                    float t[VW], y[VW];
                     Lane<T>::unpack(v[k], t);
+                    if (BWD) Lane<T>::unpack(vy[BWD ? k : 0], y);
 #pragma unroll
                     for (int j = 0; j < VW; ++j) {
-                        const float x = PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
+                        const float x = BWD ? fmaf(pa[j], t[j] * lrelu_grad(fmaf(y[j], pa[j], psh[j]), slope), fmaf(kc1[j], y[j], kc0[j]))
+                                            : PRO ? lrelu(fmaf(t[j], pa[j], psh[j]), slope) : t[j];
                         acc[j] = fmaf(wj[k], x, acc[j]);
                     }
                 }
@@ -405,26 +456,27 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
 
 // (two LDS buffers: three and four measured slower, profiles/r02_experiments)
 
-template <typename T, int KD, bool PRO, int RED, int NB>
+template <typename T, int KD, bool PRO, int RED, int NB, bool BWD = false>
 size_t patch2_lds(int C, int emax) {
     const int PR = 32 * KD;
-    const size_t buf = (size_t)PR * 128 + (RED == 1 ? kRB * 128 : 0);
+    const size_t buf = (size_t)PR * 128 * (BWD ? 2 : 1) + (RED == 1 ? kRB * 128 : 0);
     const size_t cs = 128 / sizeof(T);
     return NB * buf + (size_t)emax * 4 + kRB * 4 + (kRB + 4) * 4 + (size_t)emax * 2 + kRB * 4 +
-           (size_t)(RED == 1 ? 7 : RED == 2 ? 4 : PRO ? 3 : 1) * C * 4 + (RED ? 2 * 4 * 2 * cs * 4 : 0);
+           (size_t)(RED == 1 ? 7 : RED == 2 ? 4 : BWD ? 5 : PRO ? 3 : 1) * C * 4 + (RED ? 2 * 4 * 2 * cs * 4 : 0);
 }
 
-template <typename T, int KD, bool PRO, int RED, int NB, int NE>
+template <typename T, int KD, bool PRO, int RED, int NB, int NE, bool BWD = false>
 int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t ldy, int C, const float* bias, const float* ps,
-                    const float* psh, float slope, hipStream_t st, RedArgs red) {
+                    const float* psh, float slope, hipStream_t st, RedArgs red, BwdArgs bw = BwdArgs()) {
     const int n = (int)g->n_rows;
     const int n_chunks = (int)cdiv(n, kRB);
     const int cpx = (int)cdiv(n_chunks, kXcd);
     // the entry tables hold the graph's largest taken chunk (face graph: 256 entries, not the 1024 a chunk may have at most: 4.5 KB
     // less, a third workgroup per CU for the fused reduction at C = 256)
     const int emax = std::min(kMaxE, std::max(64, (g->max_chunk_nnz + 63) / 64 * 64));
-    const size_t lds = patch2_lds<T, KD, PRO, RED, NB>(C, emax);   // (the same for every NE)
-    auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB, NE>;
+    const size_t lds = patch2_lds<T, KD, PRO, RED, NB, BWD>(C, emax);   // (the same for every NE)
+    if (lds > 160 * 1024) return ddmp::kPatchNotApplicable;
+    auto kern = spmm_patch2_kernel<T, KD, PRO, RED, NB, NE, BWD>;
     // > 64 KB of dynamic LDS needs the attribute, once per kernel AND device (a second device of the same process -- threaded
     // ranks -- has its own copy of the function)
     static std::atomic<uint32_t> attr_done{0};
@@ -439,7 +491,7 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
         attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->ew, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, X,
-                       ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, emax, red);
+                       ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, emax, red, bw);
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -498,21 +550,28 @@ int patch_mode() {
 //   prologue C = 512 face 812 | 935, vertex 498 | 627;  reduction C = 512 face 1246 | 1284, vertex 707 | 747, C = 256 face
 //   639 | 646, vertex 370 | 394;  statistics C = 512 face 857 | 937, vertex 505 | 616, C = 256 face 432 | 469, vertex 264 | 308
 constexpr int patch_forms() { return 15; }
-
 // does ddmp_spmm* take the LDS-patch kernel for this graph and shape? (tests; the selection itself: patch_mode above)
-// has_red: 0 | 1 the BatchNorm-backward reductions | 2 the statistics form
+// has_red: 0 | 1 the BatchNorm-backward reductions | 2 the statistics form | 3 the BatchNorm backward on the gather (ddmp_spmm_bnbwd_f32)
 extern "C" int ddmp_spmm_patch_selected(const ddmp_graph* g, int C, int dtype, int has_pro, int has_red) {
     if (!g || !patch_mode() || g->max_patch <= 0 || g->max_patch > 192 || !g->lcol) return 0;
     if (has_red == 1 && has_pro) return 0;                       // (no such form)
+    // the BatchNorm backward on the gather: patches of up to 128 rows (two tensors per buffer), C <= 512 (its five coefficient
+    // rows + doubled buffers: 79 KB at C = 512 on the vertex graph, two workgroups per CU; beyond that one).  us per launch patch | lean,
+    // 1M faces, RCB order, cold buffers (profiles/r06_gather_prologue_ab.txt E): face C = 512 1117 | 1345, 256 578 | 702, 128 299 | 345;
+    // vertex 640 | 964, 335 | 473, 191 | 235
+    if (has_red == 3 && (g->patch_kd > 4 || C > 512)) return 0;
     if (patch_mode() == 3) {
         // measured selection (by_patch's note, patch_forms); row lengths are not a condition since round 5
         // round 6: float32 from C = 128 -- with the one-round-trip set-up the kernel wins there too (us per launch patch | lean, 1M faces,
         // RCB order, cold buffers: face prologue 206 | 224, statistics 226 | 244, reduction 310 | 323; vertex 138 | 149, 158 | 167,
         // 197-206 | 200); at C = 64 it loses the prologue and reduction forms (profiles/r06_gather_prologue_ab.txt)
-        if (g->max_row_nnz > patch_max_nnz() || C < (dtype == DDMP_F32 ? 128 : 256)) return 0;
+        // (bfloat16 features, round 6: plain / prologue / statistics from C = 128 too -- face prologue 120 | 146 us, statistics 139 | 172;
+        //  vertex 96 | 105, 105 | 117, profiles/r06_gather_prologue_ab.txt F)
+        if (g->max_row_nnz > patch_max_nnz() || C < 128) return 0;
         // bfloat16 features (round 5, 1M faces, RCB numbering, us per launch patch | slab kernel): plain C = 512 face 420 | 457,
         // vertex 251 | 311; prologue face 434 | 550, vertex 414 | 428; statistics face 546 | 617, vertex 377 | 425 (C = 256 alike);
-        // the fused reduction LOSES there (face 819 | 730, vertex 493 | 448) and stays on the slab kernel
+        // the fused reduction LOSES there (face 819 | 730, vertex 493 | 448; round 6 with the new set-up: 703 | 681, 421 | 431 at C = 512,
+        // 384 | 352, 235 | 224 at C = 256) and stays on the slab kernel
         if (dtype != DDMP_F32 && (has_red == 1 || !(patch_forms() & 8))) return 0;
         if (has_red == 1 && !(patch_forms() & 2)) return 0;
         if (has_red == 2 && !(patch_forms() & 4)) return 0;
@@ -549,6 +608,32 @@ int spmm_patch(const ddmp_graph* g, const void* X, int64_t ldx, void* Y, int64_t
                              : by_patch<float, false, 2>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
     if (ps) return by_patch<float, true, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
     return by_patch<float, false, 0>(g, x, ldx, y, ldy, C, bias, ps, psh, slope, st, red);
+}
+
+// out = A_hat . dY with dY the BatchNorm + LeakyReLU backward of (dZ, Yb) rebuilt on the gather: LDS-patch form.  The caller
+// processes g->heavy with the lean kernel's BWD form.
+int spmm_patch_bwd(const ddmp_graph* g, const void* dZ, int64_t lddz, const void* Yb, int64_t ldyb, void* out, int64_t ld_out, int C,
+                   int dtype, const float* a, const float* b, const float* c1, const float* c0, float slope, hipStream_t st) {
+    if (!ddmp_spmm_patch_selected(g, C, dtype, 1, 3)) return kPatchNotApplicable;
+    BwdArgs bw{Yb, ldyb, c1, c0};
+    RedArgs red{};
+    const bool ne4 = g->max_row_nnz <= 4;
+#define DDMP_PBWD(T_, KD_, NE_)                                                                                                  \
+    launch_patch2nb<T_, KD_, true, 0, 2, NE_, true>(g, static_cast<const T_*>(dZ), lddz, static_cast<T_*>(out), ld_out, C, nullptr, a, b, \
+                                                    slope, st, red, bw)
+    if (dtype == DDMP_BF16) {
+        switch (g->patch_kd) {
+            case 3: return !patch_ne() ? DDMP_PBWD(bf16_t, 3, 0) : ne4 ? DDMP_PBWD(bf16_t, 3, 4) : DDMP_PBWD(bf16_t, 3, 8);
+            case 4: return !patch_ne() ? DDMP_PBWD(bf16_t, 4, 0) : ne4 ? DDMP_PBWD(bf16_t, 4, 4) : DDMP_PBWD(bf16_t, 4, 8);
+            default: return kPatchNotApplicable;
+        }
+    }
+    switch (g->patch_kd) {
+        case 3: return !patch_ne() ? DDMP_PBWD(float, 3, 0) : ne4 ? DDMP_PBWD(float, 3, 4) : DDMP_PBWD(float, 3, 8);
+        case 4: return !patch_ne() ? DDMP_PBWD(float, 4, 0) : ne4 ? DDMP_PBWD(float, 4, 4) : DDMP_PBWD(float, 4, 8);
+        default: return kPatchNotApplicable;
+    }
+#undef DDMP_PBWD
 }
 
 }  // namespace ddmp

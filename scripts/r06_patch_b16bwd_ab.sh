@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 6: bfloat16 BatchNorm backward on the gather: LDS-patch form (default) against the slab kernel (DDMP_SPMM_PATCH=0: read the bn-backward column only)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+( timeout 900 python3 -m pytest tests/test_gpu_kernels.py tests/test_gpu_bf16.py tests/test_gpu_irregular.py -q -m gpu -p no:cacheprovider -x -k "spmm or gather or irregular and not under_switch" 2>&1 | tail -5 ) > $O/r06_pbb_tests.txt 2>&1
+cat $O/r06_pbb_tests.txt
+rm -f $O/r06_b16bwd_ab.txt
+for rep in 1 2; do
+  for m in slab patch; do
+    if [ $m = slab ]; then export DDMP_SPMM_PATCH=0; else unset DDMP_SPMM_PATCH; fi
+    echo "== $m (round $rep)" >> $O/r06_b16bwd_ab.txt
+    timeout 600 python3 scripts/microbench.py spmm --dtype bf16 --order rcb --rotate 3 --widths 512,256,128 --iters 12 2>/dev/null | grep "^spmm" | sed 's/plain.*reduction/.../' >> $O/r06_b16bwd_ab.txt
+  done
+done
+unset DDMP_SPMM_PATCH
+cat $O/r06_b16bwd_ab.txt
+B="--no-cpu-baseline --extras 0 --bf16-extra 0 --profile-steps 0 --mode-ab 0 --parity 0 --steps 20 --warmup 5 --dtype bf16"
+for rep in 1 2; do
+  for lib in new2 new; do
+    if [ $lib = new2 ]; then export DDMP_LIB=$R/experiments/tmp/libddmp_new2.so; else unset DDMP_LIB; fi
+    ms=$(timeout 300 python3 bench.py $B 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['ms_per_step'], d['loss'])")
+    echo "1M faces bf16, $lib: ms_per_step, loss = $ms" | tee -a $O/r06_b16bwd_ab.txt
+  done
+done

@@ -106,11 +106,11 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
         assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
         if os.environ.get("DDMP_SPMM_PATCH") is None:
             # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256;
-            # round 6 (one-round-trip chunk set-up): float32 from C = 128, nothing at C = 64, bfloat16 as before
+            # round 6 (one-round-trip chunk set-up): from C = 128, nothing at C = 64; bfloat16: not its fused reduction, as before
             assert L.ddmp_spmm_patch_selected(g._h, 512, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 0) == 1
             assert L.ddmp_spmm_patch_selected(g._h, 128, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 128, 0, 1, 2) == 1
             assert L.ddmp_spmm_patch_selected(g._h, 64, 0, 0, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 64, 0, 0, 1) == 0
-            assert L.ddmp_spmm_patch_selected(g._h, 128, 1, 0, 0) == 0 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0
+            assert L.ddmp_spmm_patch_selected(g._h, 128, 1, 0, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 1) == 0     # bf16
             assert L.ddmp_spmm_patch_selected(g._h, 256, 1, 0, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 1, 1, 2) == 1    # bf16
             assert L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 1) == 1 and L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 2) == 1
         # float64 reference: D^-1/2 (A + I) D^-1/2 as a sparse matrix
@@ -133,6 +133,26 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
                 bn4 = torch.stack([torch.rand(C) + 0.5, torch.randn(C), torch.randn(C), torch.rand(C) + 0.5]).to(dev)
                 ops.spmm_bnred(g, x.to(dev), out, torch.randn(n, C, device=dev), bn4, torch.zeros(2 * C, dtype=torch.float64, device=dev))
                 assert torch.equal(out, y)
+                # round 6: the BatchNorm backward on the gather takes the LDS-patch kernel too (two tensors per buffer): the
+                # same sums in the same order as bn_bwd_apply followed by the plain gather
+                if os.environ.get("DDMP_SPMM_PATCH") is None:
+                    assert L.ddmp_spmm_patch_selected(g._h, C, 0, 1, 3) == 1 and L.ddmp_spmm_patch_selected(g._h, 64, 0, 1, 3) == 0
+                dz, yb = torch.randn(n, C, device=dev), torch.randn(n, C, device=dev) * 2 + 0.5
+                c10 = torch.stack([torch.randn(C) * 0.1, torch.randn(C) * 0.1]).to(dev)
+                ops.spmm_bnbwd(g, dz, yb, bn4, c10, out)
+                dy = torch.empty_like(dz)
+                ops.bn_bwd_apply(dz, yb, bn4, c10, dy, torch.empty(2 * C, dtype=torch.float64, device=dev))
+                assert torch.equal(out, ops.spmm(g, dy))
+                # ... and with bfloat16 features (same form of the kernel; against float64 to the rounding of the stored output)
+                zb, yb16 = dz.to(torch.bfloat16), yb.to(torch.bfloat16)
+                o16 = torch.empty(n, C, dtype=torch.bfloat16, device=dev)
+                ops.spmm_bnbwd(g, zb, yb16, bn4, c10, o16)
+                a_, b_, k1, k0 = (t.double().cpu() for t in (bn4[0], bn4[1], c10[0], c10[1]))
+                yd, zd = yb16.double().cpu(), zb.double().cpu()
+                dyr = a_ * zd * torch.where(yd * a_ + b_ > 0, 1.0, 0.01) + k1 * yd + k0
+                assert relerr(o16, torch.sparse.mm(A, dyr)) < 3e-3
+                if os.environ.get("DDMP_SPMM_PATCH") is None:
+                    assert L.ddmp_spmm_patch_selected(g._h, C, 1, 1, 3) == 1
 
 
 @pytest.mark.parametrize("C", [32, 256, 8])
