@@ -188,12 +188,35 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
                 for (int64_t c = 0; c < n_chunks; ++c) heavy += np_of[(size_t)c] > 32 * kd;
                 if (heavy * 100 <= n_chunks) break;
             }
-            std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, heavy;
+            std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, heavy, split((size_t)2 * n_chunks, 0), tmp2;
+            int n_split = 0;
             std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1), 0);
             int max_patch = 0;
             for (int64_t c = 0; c < n_chunks; ++c) {
                 const int np = np_of[(size_t)c];
-                if (np == 0 || np > 32 * kd) {
+                const int64_t c0 = c * ddmp::kChunkRows, c1 = std::min<int64_t>(n_rows, c0 + ddmp::kChunkRows), cm = c0 + ddmp::kChunkRows / 2;
+                bool halves = false;                             // too large a patch: do its two 32-row halves fit?
+                if (np > 32 * kd && np != INT32_MAX && c1 > cm && rowptr[cm] > rowptr[c0] && rowptr[c1] > rowptr[cm]) {
+                    tmp.assign(col + rowptr[c0], col + rowptr[cm]);
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    tmp2.assign(col + rowptr[cm], col + rowptr[c1]);
+                    std::sort(tmp2.begin(), tmp2.end());
+                    tmp2.erase(std::unique(tmp2.begin(), tmp2.end()), tmp2.end());
+                    halves = (int)tmp.size() <= 32 * kd && (int)tmp2.size() <= 32 * kd;
+                }
+                if (halves) {
+                    max_patch = std::max(max_patch, (int)std::max(tmp.size(), tmp2.size()));
+                    g->max_chunk_nnz = std::max(g->max_chunk_nnz, (int)(rowptr[c1] - rowptr[c0]));
+                    for (int64_t e2 = rowptr[c0]; e2 < rowptr[cm]; ++e2)
+                        lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
+                    for (int64_t e2 = rowptr[cm]; e2 < rowptr[c1]; ++e2)
+                        lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp2.begin(), tmp2.end(), col[e2]) - tmp2.begin());
+                    pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
+                    split[(size_t)2 * c] = (int32_t)pl_col.size();           // (> 0: the first half's patch is not empty)
+                    split[(size_t)2 * c + 1] = (int32_t)(n_chunks + n_split++);
+                    pl_col.insert(pl_col.end(), tmp2.begin(), tmp2.end());
+                } else if (np == 0 || np > 32 * kd) {
                     heavy.push_back((int32_t)c);
                 } else {
                     const int64_t r0 = c * ddmp::kChunkRows, r1 = std::min<int64_t>(n_rows, r0 + ddmp::kChunkRows);
@@ -215,6 +238,11 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
                 if ((e = hipMemcpy(g->pl_ptr, pl_ptr.data(), sizeof(int32_t) * pl_ptr.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
                 if ((e = hipMemcpy(g->pl_col, pl_col.data(), sizeof(int32_t) * pl_col.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
                 if ((e = hipMemcpy(g->lcol, lcol.data(), sizeof(uint16_t) * lcol.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                if (n_split > 0) {
+                    if ((e = hipMalloc((void**)&g->pl_split, sizeof(int32_t) * split.size())) != hipSuccess) goto fail;
+                    if ((e = hipMemcpy(g->pl_split, split.data(), sizeof(int32_t) * split.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
+                    g->n_split = n_split;
+                }
                 if (!heavy.empty()) {
                     if ((e = hipMalloc((void**)&g->heavy, sizeof(int32_t) * heavy.size())) != hipSuccess) goto fail;
                     if ((e = hipMemcpy(g->heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice)) != hipSuccess) goto fail;
@@ -296,6 +324,7 @@ extern "C" int ddmp_graph_destroy(ddmp_graph* g) {
     if (g->pl_col) (void)hipFree(g->pl_col);
     if (g->lcol) (void)hipFree(g->lcol);
     if (g->ew) (void)hipFree(g->ew);
+    if (g->pl_split) (void)hipFree(g->pl_split);
     if (g->heavy) (void)hipFree(g->heavy);
     delete g;
     return DDMP_OK;
@@ -308,6 +337,14 @@ extern "C" int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_
     if (n_cols) *n_cols = g->n_cols;
     if (nnz) *nnz = g->nnz;
     if (max_row_nnz) *max_row_nnz = g->max_row_nnz;
+    return DDMP_OK;
+}
+
+extern "C" int ddmp_graph_patch_info(const ddmp_graph* g, int* patch_kd, int* n_heavy, int* n_split) {
+    ARG_TRY(g);
+    if (patch_kd) *patch_kd = g->max_patch > 0 ? g->patch_kd : 0;
+    if (n_heavy) *n_heavy = g->n_heavy;
+    if (n_split) *n_split = g->n_split;
     return DDMP_OK;
 }
 

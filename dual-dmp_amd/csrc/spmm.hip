@@ -529,7 +529,7 @@ extern "C" int ddmp_spmm_bnred_f32(const ddmp_graph* g, const float* X, int64_t 
                                               g->heavy, g->n_heavy);
         if (rc == DDMP_OK) {
             const size_t pb2 = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-            fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pb2), sums2, st);
+            fpartials_reduce((const float*)ws, n_chunks + g->n_split, C, C, (double*)((char*)ws + pb2), sums2, st);   // (+ the split chunks' second records)
             LAUNCH_TRY();
             return DDMP_OK;
         }
@@ -587,7 +587,9 @@ extern "C" int ddmp_spmm_stats_f32(const ddmp_graph* g, const float* X, int64_t 
                                                       list, g->n_heavy);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)lp.n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, lp.n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);
+    // (a split chunk of the LDS-patch kernel has a second record behind the chunks': the records' area is sized for four per chunk)
+    fpartials_reduce((const float*)ws, lp.n_chunks + (patched ? g->n_split : 0), C, C, (double*)((char*)ws + pbytes), sums2, st, ref,
+                     (double)g->n_rows);
     LAUNCH_TRY();
     return DDMP_OK;
 }

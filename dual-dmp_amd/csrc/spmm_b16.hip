@@ -444,6 +444,7 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
     BnRedB red{Yp, ldyp, scale, shift, mean, rstd, (float*)ws};
     int rc = ddmp::spmm_patch(g, X, ldx, Y, ldy, C, DDMP_BF16, nullptr, nullptr, nullptr, slope, Yp, ldyp, scale, shift, mean, rstd,
                               (float*)ws, st);
+    const bool patched = rc == DDMP_OK;
     if (rc == DDMP_OK && g->n_heavy > 0)
         rc = dispatch_b16<false, 1, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red, BnBwdGatherB(), g->heavy,
                                            g->n_heavy);
@@ -451,7 +452,7 @@ extern "C" int ddmp_spmm_bnred_bf16(const ddmp_graph* g, const uint16_t* X, int6
         rc = dispatch_b16<false, 1, false>(g, X, ldx, Y, ldy, C, nullptr, nullptr, nullptr, slope, st, red);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st);    // (one record per chunk, both kernels)
+    fpartials_reduce((const float*)ws, n_chunks + (patched ? g->n_split : 0), C, C, (double*)((char*)ws + pbytes), sums2, st);    // (one record per chunk, both kernels; + the LDS-patch kernel's split chunks)
     LAUNCH_TRY();
     return DDMP_OK;
 }
@@ -485,7 +486,8 @@ extern "C" int ddmp_spmm_stats_bf16(const ddmp_graph* g, const uint16_t* X, int6
                                                        list, g->n_heavy);
     if (rc != DDMP_OK) return rc;
     const size_t pbytes = ((size_t)n_chunks * 4 * 2 * (size_t)C * sizeof(float) + 255) / 256 * 256;
-    fpartials_reduce((const float*)ws, n_chunks, C, C, (double*)((char*)ws + pbytes), sums2, st, ref, (double)g->n_rows);    // (one record per chunk)
+    fpartials_reduce((const float*)ws, n_chunks + (patched ? g->n_split : 0), C, C, (double*)((char*)ws + pbytes), sums2, st, ref,
+                     (double)g->n_rows);    // (one record per chunk; + the LDS-patch kernel's split chunks)
     LAUNCH_TRY();
     return DDMP_OK;
 }

@@ -87,7 +87,7 @@ struct BwdArgs {                    // BatchNorm backward on the gather (see BnB
 template <typename T, int KD, bool PRO, int RED, int NB, int NE, bool BWD = false>
 __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const unsigned short* __restrict__ lcol,
-    const float* __restrict__ ew, const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col,
+    const float* __restrict__ ew, const float* __restrict__ dinv, const float* __restrict__ dinv_r, const int* __restrict__ pl_ptr, const int* __restrict__ pl_col, const int* __restrict__ pl_split,
     const T* __restrict__ X, int64_t ldx, T* __restrict__ Y, int64_t ldy, int n_rows, int C,
     const float* __restrict__ bias, const float* __restrict__ pscale, const float* __restrict__ pshift, float slope,
     int chunks_per_xcd, int n_chunks, int emax, RedArgs red, BwdArgs bw = BwdArgs()) {
@@ -116,8 +116,6 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
 
     const int chunk = (blockIdx.x & (kXcd - 1)) * chunks_per_xcd + (blockIdx.x >> 3);
     if (chunk >= n_chunks) return;
-    const int r0 = chunk * kRB;
-    const int nr = min(kRB, n_rows - r0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,8 +126,22 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     // are issued as soon as those arrive --, every table of the chunk (row pointers, factors, the entries' patch indices and their
     // weights `ew` = dinv[col[e]], precomputed per graph: no col -> dinv chain) is requested before that wait and lands in LDS
     // while slab 0 travels.  (Before: row pointers + patch list -> barrier -> col -> dinv[col] -> barrier -> first copy.)
-    const int p0 = pl_ptr[chunk], np = pl_ptr[chunk + 1] - p0;
-    if (np <= 0) return;                                         // a heavy chunk: the lean gather's (uniform: before any barrier)
+    const int pl0 = pl_ptr[chunk], pl1 = pl_ptr[chunk + 1];
+    if (pl1 <= pl0) return;                                      // a heavy chunk: the lean gather's (uniform: before any barrier)
+    // a SPLIT chunk (ddmp_graph::pl_split: its patch is too large, the patches of its two 32-row halves fit) is walked in two passes,
+    // each a chunk of 32 rows with its own patch, entry indices and -- fused sums -- record slot
+    int mid = 0, rec2 = 0;
+    if (pl_split) {
+        mid = pl_split[2 * chunk];
+        rec2 = pl_split[2 * chunk + 1];
+    }
+    const int nh = mid > 0 ? 2 : 1;
+    const int rows_c = min(kRB, n_rows - chunk * kRB);
+    for (int h = 0; h < nh; ++h) {
+    const int r0 = chunk * kRB + (kRB / 2) * h;
+    const int nr = nh == 1 ? rows_c : (h == 0 ? kRB / 2 : rows_c - kRB / 2);
+    const int p0 = h ? mid : pl0, np = ((nh == 2 && h == 0) ? mid : pl1) - p0;
+    const int rec = h ? rec2 : chunk;
     const int e0 = rowptr[r0];
     const int ne = rowptr[r0 + nr] - e0;                         // <= kMaxE (graph.hip: a chunk with more entries is heavy)
     const T* xlane = X + sl * VW;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         const int which = i / CS, c = i % CS;
         const float* sp = s_part + ((s & 1) * 4 * 2) * CS + which * CS + c;
         const double t = ((double)sp[0] + (double)sp[2 * CS]) + ((double)sp[4 * CS] + (double)sp[6 * CS]);
-        if (lane < Q) red.part[((int64_t)chunk * 2 + which) * C + s * CS + c] = (float)t;
+        if (lane < Q) red.part[((int64_t)rec * 2 + which) * C + s * CS + c] = (float)t;
     };
     auto slab = [&](int s, auto bc) {
         constexpr int B = decltype(bc)::value;
@@ -451,6 +463,8 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
         __syncthreads();
         record(n_slabs - 1);
     }
+    if (h + 1 < nh) __syncthreads();                             // (every wave is done with the tables and buffers of this pass)
+    }
     // (every copy was waited for by the slab that reads it; what is in flight here are stores: nothing to wait for)
 }
 
@@ -490,7 +504,7 @@ int launch_patch2nb(const ddmp_graph* g, const T* X, int64_t ldx, T* Y, int64_t 
         }
         attr_done.fetch_or(1u << dev, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->ew, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, X,
+    hipLaunchKernelGGL(kern, dim3(cpx * kXcd), dim3(256), lds, st, g->rowptr, g->col, g->lcol, g->ew, g->dinv, g->dinv_r, g->pl_ptr, g->pl_col, g->pl_split, X,
                        ldx, Y, ldy, n, C, bias, ps, psh, slope, cpx, n_chunks, emax, red, bw);
     LAUNCH_TRY();
     return DDMP_OK;

@@ -103,6 +103,13 @@ def test_spmm_lds_patch_route_on_a_large_face_graph(dev):
     for ei, n in ((fi, len(f)), (vi, len(v))):
         g = ops.graph_for(ei.to(dev), n)
         sel = L.ddmp_spmm_patch_selected(g._h, 256, 0, 0, 0) == 1       # (144,400 faces / 72,200 vertices: both from 64k rows)
+        if os.environ.get("DDMP_SPMM_PATCH") is None:
+            # round 6: the chunks of a regular mesh whose patch exceeds the LDS buffers are walked as two 32-row halves inside the same
+            # launch (this mesh has some, so the comparisons below cover that path): no heavy list, no second launch per aggregation
+            import ctypes
+            kd, nh, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            assert L.ddmp_graph_patch_info(g._h, ctypes.byref(kd), ctypes.byref(nh), ctypes.byref(ns)) == 0
+            assert kd.value in (3, 4) and nh.value == 0 and ns.value > 0, (kd.value, nh.value, ns.value)
         assert sel and L.ddmp_spmm_patch_selected(g._h, 256, 0, 1, 0) == 1 and L.ddmp_spmm_patch_selected(g._h, 512, 0, 0, 0) == 1
         if os.environ.get("DDMP_SPMM_PATCH") is None:
             # round 5: also the prologue at C = 512, the fused reduction at C = 512 and the statistics form from C = 256;
