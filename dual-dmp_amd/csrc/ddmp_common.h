@@ -199,11 +199,12 @@ struct ddmp_graph {
     int max_chunk_nnz;  // most CSR entries of a chunk the patch kernel takes (its LDS entry tables are sized for it)
     int max_patch;      // largest patch among the chunks the patch kernel takes (0: tables not built)
     int patch_kd;       // patch rows per LDS buffer / 32 (3..6), chosen so that at most ~1 % of the chunks are heavy
-    // round 6: a chunk whose patch is too large but whose two 32-row HALVES each fit is "split": the patch kernel walks it in two passes
-    // (pl_split[2c] = start of the second half's patch in pl_col, 0 for every other chunk; pl_split[2c + 1] = the record slot of the
-    // second half's fused sums, n_chunks + its rank) -- on a regular mesh that leaves no heavy chunk, i.e. no second launch per gather
-    int32_t* pl_split;  // device [2 * n_chunks] (nullptr: no split chunk)
-    int n_split;
+    // round 6: a chunk whose patch is too large but whose 2 halves (32 rows) or 4 quarters (16 rows) each fit is "split": the patch
+    // kernel walks it in as many passes.  pl_split[2c + 1] = parts (0: not split), pl_split[2c] = index IN pl_split of the chunk's
+    // (patch start in pl_col, record slot of the part's fused sums) pairs for parts 1 ..; record slots are n_chunks + 0 .. n_split - 1.
+    // On a regular mesh that leaves no heavy chunk, i.e. no second launch per gather
+    int32_t* pl_split;  // device [2 * n_chunks + 2 * n_split] (nullptr: no split chunk)
+    int n_split;        // extra record slots = sum over the split chunks of (parts - 1)
     int32_t* heavy;     // device [n_heavy]: the heavy chunks, ascending
     int n_heavy;
 };

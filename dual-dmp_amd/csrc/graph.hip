@@ -188,34 +188,47 @@ static int upload_graph(int64_t n_rows, int64_t n_cols, const int32_t* rowptr, c
                 for (int64_t c = 0; c < n_chunks; ++c) heavy += np_of[(size_t)c] > 32 * kd;
                 if (heavy * 100 <= n_chunks) break;
             }
-            std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, heavy, split((size_t)2 * n_chunks, 0), tmp2;
+            std::vector<int32_t> pl_ptr((size_t)n_chunks + 1, 0), pl_col, heavy, split((size_t)2 * n_chunks, 0);
             int n_split = 0;
             std::vector<uint16_t> lcol((size_t)std::max<int64_t>(g->nnz, 1), 0);
             int max_patch = 0;
             for (int64_t c = 0; c < n_chunks; ++c) {
                 const int np = np_of[(size_t)c];
-                const int64_t c0 = c * ddmp::kChunkRows, c1 = std::min<int64_t>(n_rows, c0 + ddmp::kChunkRows), cm = c0 + ddmp::kChunkRows / 2;
-                bool halves = false;                             // too large a patch: do its two 32-row halves fit?
-                if (np > 32 * kd && np != INT32_MAX && c1 > cm && rowptr[cm] > rowptr[c0] && rowptr[c1] > rowptr[cm]) {
-                    tmp.assign(col + rowptr[c0], col + rowptr[cm]);
-                    std::sort(tmp.begin(), tmp.end());
-                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                    tmp2.assign(col + rowptr[cm], col + rowptr[c1]);
-                    std::sort(tmp2.begin(), tmp2.end());
-                    tmp2.erase(std::unique(tmp2.begin(), tmp2.end()), tmp2.end());
-                    halves = (int)tmp.size() <= 32 * kd && (int)tmp2.size() <= 32 * kd;
+                const int64_t c0 = c * ddmp::kChunkRows, c1 = std::min<int64_t>(n_rows, c0 + ddmp::kChunkRows);
+                int parts = 0;                                   // too large a patch: do its 2 halves (32 rows) or 4 quarters (16 rows) fit?
+                if (np > 32 * kd && np != INT32_MAX) {
+                    for (int nh = 2; nh <= 4 && !parts; nh *= 2) {
+                        const int64_t rp = ddmp::kChunkRows / nh;
+                        bool fit = c1 - c0 > rp * (nh - 1);      // (every part has rows)
+                        for (int h = 0; h < nh && fit; ++h) {
+                            const int64_t a0 = c0 + rp * h, a1 = std::min<int64_t>(c1, a0 + rp);
+                            tmp.assign(col + rowptr[a0], col + rowptr[a1]);
+                            std::sort(tmp.begin(), tmp.end());
+                            const int64_t u = std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+                            fit = u > 0 && u <= 32 * kd;         // (a part without entries has no patch row to point at)
+                        }
+                        if (fit) parts = nh;
+                    }
                 }
-                if (halves) {
-                    max_patch = std::max(max_patch, (int)std::max(tmp.size(), tmp2.size()));
+                if (parts) {
+                    const int64_t rp = ddmp::kChunkRows / parts;
                     g->max_chunk_nnz = std::max(g->max_chunk_nnz, (int)(rowptr[c1] - rowptr[c0]));
-                    for (int64_t e2 = rowptr[c0]; e2 < rowptr[cm]; ++e2)
-                        lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
-                    for (int64_t e2 = rowptr[cm]; e2 < rowptr[c1]; ++e2)
-                        lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp2.begin(), tmp2.end(), col[e2]) - tmp2.begin());
-                    pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
-                    split[(size_t)2 * c] = (int32_t)pl_col.size();           // (> 0: the first half's patch is not empty)
-                    split[(size_t)2 * c + 1] = (int32_t)(n_chunks + n_split++);
-                    pl_col.insert(pl_col.end(), tmp2.begin(), tmp2.end());
+                    split[(size_t)2 * c] = (int32_t)split.size();            // this chunk's (patch start, record slot) pairs, parts 1 ..
+                    split[(size_t)2 * c + 1] = parts;
+                    for (int h = 0; h < parts; ++h) {
+                        const int64_t a0 = c0 + rp * h, a1 = std::min<int64_t>(c1, a0 + rp);
+                        tmp.assign(col + rowptr[a0], col + rowptr[a1]);
+                        std::sort(tmp.begin(), tmp.end());
+                        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                        max_patch = std::max(max_patch, (int)tmp.size());
+                        for (int64_t e2 = rowptr[a0]; e2 < rowptr[a1]; ++e2)
+                            lcol[(size_t)e2] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), col[e2]) - tmp.begin());
+                        if (h > 0) {
+                            split.push_back((int32_t)pl_col.size());
+                            split.push_back((int32_t)(n_chunks + n_split++));
+                        }
+                        pl_col.insert(pl_col.end(), tmp.begin(), tmp.end());
+                    }
                 } else if (np == 0 || np > 32 * kd) {
                     heavy.push_back((int32_t)c);
                 } else {

@@ -128,20 +128,21 @@ __global__ __launch_bounds__(256) void spmm_patch2_kernel(
     // while slab 0 travels.  (Before: row pointers + patch list -> barrier -> col -> dinv[col] -> barrier -> first copy.)
     const int pl0 = pl_ptr[chunk], pl1 = pl_ptr[chunk + 1];
     if (pl1 <= pl0) return;                                      // a heavy chunk: the lean gather's (uniform: before any barrier)
-    // a SPLIT chunk (ddmp_graph::pl_split: its patch is too large, the patches of its two 32-row halves fit) is walked in two passes,
-    // each a chunk of 32 rows with its own patch, entry indices and -- fused sums -- record slot
-    int mid = 0, rec2 = 0;
+    // a SPLIT chunk (ddmp_graph::pl_split: its patch is too large, the patches of its 2 halves / 4 quarters fit) is walked in as many
+    // passes, each a chunk of 32 / 16 rows with its own patch, entry indices and -- fused sums -- record slot
+    int nh = 1, first = 0;
     if (pl_split) {
-        mid = pl_split[2 * chunk];
-        rec2 = pl_split[2 * chunk + 1];
+        first = pl_split[2 * chunk];
+        nh = max(1, pl_split[2 * chunk + 1]);
     }
-    const int nh = mid > 0 ? 2 : 1;
+    const int rp = kRB / nh;
     const int rows_c = min(kRB, n_rows - chunk * kRB);
     for (int h = 0; h < nh; ++h) {
-    const int r0 = chunk * kRB + (kRB / 2) * h;
-    const int nr = nh == 1 ? rows_c : (h == 0 ? kRB / 2 : rows_c - kRB / 2);
-    const int p0 = h ? mid : pl0, np = ((nh == 2 && h == 0) ? mid : pl1) - p0;
-    const int rec = h ? rec2 : chunk;
+    const int r0 = chunk * kRB + rp * h;
+    const int nr = min(rp, rows_c - rp * h);                     // (> 0: the table builder splits only chunks whose every part has rows)
+    const int p0 = h ? pl_split[first + 2 * (h - 1)] : pl0;
+    const int np = (h + 1 < nh ? pl_split[first + 2 * h] : pl1) - p0;
+    const int rec = h ? pl_split[first + 2 * (h - 1) + 1] : chunk;
     const int e0 = rowptr[r0];
     const int ne = rowptr[r0 + nr] - e0;                         // <= kMaxE (graph.hip: a chunk with more entries is heavy)
     const T* xlane = X + sl * VW;

@@ -82,8 +82,8 @@ int ddmp_graph_create_csr_rows_host(int64_t n_rows_all, int64_t n_cols, const in
 int ddmp_graph_destroy(ddmp_graph* g);
 int ddmp_graph_info(const ddmp_graph* g, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int* max_row_nnz);
 /* How the LDS-patch gather takes this graph's 64-row chunks: patch_kd = patch rows per LDS buffer / 32 (0: no patch tables,
- * every aggregation runs the lean gather), n_heavy = chunks that go to the lean gather in a second launch, n_split = chunks walked as two
- * 32-row halves inside the same launch.  Diagnostic (tests, DESIGN figures); any pointer may be NULL. */
+ * every aggregation runs the lean gather), n_heavy = chunks that go to the lean gather in a second launch, n_split = the extra passes of the chunks walked
+ * as 2 halves / 4 quarters inside the same launch (= their extra record slots).  Diagnostic (tests, DESIGN figures); any pointer may be NULL. */
 int ddmp_graph_patch_info(const ddmp_graph* g, int* patch_kd, int* n_heavy, int* n_split);
 
 /* ------------------------------------------------------------------ aggregation  Y = A_hat . f(X) (+ bias)
