@@ -11,10 +11,10 @@ for l in raw:
     m = re.match(r"void (\S.*?)\s+grid (\d+)\s+(\S+)\s+launches\s+(\d+)\s+sum (\S+)\s+per launch (\S+)", l)
     if m:
         rows.setdefault((m.group(1).strip(), int(m.group(2))), {})[m.group(3)] = float(m.group(6))
-print("# scripts/spmm_pmc.sh %d on one MI355X (round 5): TCP / TCC / SQ counters of the plain gather at C = %d on the 1M-face torus in RCB" % (C, C))
+print("# scripts/r06_gather_counters.sh %d (= scripts/archive/spmm_pmc.sh) on one MI355X: TCP / TCC / SQ counters of the plain gather at C = %d on the 1M-face torus in RCB" % (C, C))
 print("# order (the engines' numbering): 3 launches each on the FACE graph (1,000,000 rows x 4 entries) and the VERTEX graph (500,000 rows x 7")
-print("# entries).  The wide launches run spmm_patch2_kernel (LDS-patch gather: NE = 4 | 8 register entries); the small")
-print("# spmm_lean_kernel launches beside them are the heavy-chunk lists (chunks whose patch exceeds the LDS buffers: ddmp_graph::heavy).")
+print("# entries).  The wide launches run spmm_patch2_kernel (LDS-patch gather: NE = 4 | 8 register entries); small spmm_lean_kernel")
+print("# launches beside them, if any, are heavy-chunk lists (round 5; since round 6 oversized chunks of a regular mesh are split inside the launch).")
 print("# Seven rocprofv3 --pmc passes (kernel trace only), sums over the device, per launch and OUTPUT ROW (%d bytes of output).\n" % (4 * C))
 for (k, grid), c in sorted(rows.items(), key=lambda kv: -kv[0][1]):
     n_rows = {4001792: 1000000, 2000896: 500000}.get(grid)
