@@ -269,6 +269,42 @@ def test_gather_forms_on_random_csr_graphs(dev, seed, n, nc, band, C):
         _forms(dev, gr, C, dtype, tol)
 
 
+@pytest.mark.parametrize("C", [256, 128])
+def test_oversized_chunks_are_split_into_halves_or_quarters(dev, C):
+    """Round 6: a chunk whose patch (distinct referenced rows) exceeds the LDS buffers of the LDS-patch gather is walked as 2 halves or
+    4 quarters inside the same launch when every part fits; only what does not fit even then goes to the lean gather's heavy list.
+    A designed graph: 70,400 rows with 4 local entries each (patches of ~70 rows: patch_kd = 3, 96-row buffers), and three chunks
+    whose rows reference far-apart columns -- 2 distinct per row (whole patch 128: halves of 64 fit), 5 per row (halves 160,
+    quarters 80 fit), 8 per row (quarters 128: stays heavy).  Every form against float64, float32 and bfloat16."""
+    import ctypes
+    from dual_dmp_amd import _lib
+    if os.environ.get("DDMP_SPMM_PATCH") == "0":
+        pytest.skip("LDS-patch gather switched off")
+    n = 70400
+    rng = np.random.default_rng(5)
+    rows_cols = []
+    special = {100: 2, 500: 5, 900: 8}                            # chunk -> distinct far columns per row
+    for c in range(n // 64):
+        r = np.arange(64 * c, 64 * c + 64)
+        k = special.get(c)
+        if k is None:
+            cols = np.stack([r, np.clip(r + 1, 0, n - 1), np.clip(r - 1, 0, n - 1), np.clip(r + 3, 0, n - 1)], 1)
+        else:                                                     # row i of the chunk: k columns nobody else in the chunk references
+            cols = (np.arange(64 * k).reshape(64, k) * 97 + 1000 * c) % n
+        rows_cols.append(cols)
+    lens = np.array([len(x) for cc in rows_cols for x in cc])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.asarray(x) for cc in rows_cols for x in cc]).astype(np.int32)
+    dinv = (rng.random(n) * 0.9 + 0.1).astype(np.float32)
+    gr = G(dev, rowptr, col, dinv, n)
+    if os.environ.get("DDMP_SPMM_PATCH") is None:
+        kd, nh, ns = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert _lib.lib().ddmp_graph_patch_info(gr.g._h, ctypes.byref(kd), ctypes.byref(nh), ctypes.byref(ns)) == 0
+        assert (kd.value, nh.value, ns.value) == (3, 1, 1 + 3), (kd.value, nh.value, ns.value)
+    for dtype, tol in ((torch.float32, 3e-6), (torch.bfloat16, 4e-3)):
+        _forms(dev, gr, C, dtype, tol)
+
+
 class GSlice(G):
     """Rows [r0, r1) of a graph as a graph of their own (ops.Graph.from_csr_host(rows=...), ddmp_graph_create_csr_rows_host): the
     interior / boundary halves of a partitioned graph (dist.py, round 6).  Output row i is node r0 + i; the columns keep the
