@@ -211,8 +211,11 @@ def test_split_aggregation_matches_unsplit_and_unpartitioned(monkeypatch, oracle
             _compare(ref[0], results[r], ref, "split%s rank%d" % (split, r))
     for r in range(P):
         for (l1, p1, n1), (l0, p0, n0) in zip(runs["1"][r][0], runs["0"][r][0]):
-            assert abs(l1 - l0) <= 5e-7 * abs(l0)             # (float32 outputs of the stub: rounding of the added sums)
-            assert float((p1 - p0).abs().max()) < 5e-6 and float((n1 - n0).abs().max()) < 5e-6
+            assert abs(l1 - l0) <= 2e-6 * abs(l0)             # (float32 outputs of the stub: rounding of the added sums)
+            # (rounding level of the values themselves: positions here reach |p| ~ 17, one float32 ulp there is 1.9e-6, and how the CPU
+            #  kernels of torch associate their sums depends on the threads the process happens to run them on: 5.7e-6 was seen once)
+            ptol = 2e-6 * max(1.0, float(p0.abs().max()))
+            assert float((p1 - p0).abs().max()) <= ptol and float((n1 - n0).abs().max()) <= 1e-5, (ptol, float((p1 - p0).abs().max()))
 
 
 def _gloo_worker(rank, world, port, q, interleave="0", losses="replicated", kind="ico2"):
